@@ -1,0 +1,152 @@
+/*
+ * spectralkernels_hip.h -- C ABI of the MI355X-native kernel_values hot path.
+ *
+ * Drop-in boundary for SpectralKernels.jl's exported API (src/SpectralKernels.jl:12):
+ *   AdaptiveKernelConfig(f; kwargs...)           src/adaptive.jl:24-59
+ *   compute_k0(config)                           src/adaptive.jl:74-91
+ *   kernel_values(config, xs; k0, param_derivative, verbose) -> (vals, errs)
+ *                                                src/adaptive.jl:95-108
+ * and, for tests, the narrowest internal seam finufft1d3(w, s, x) (src/utils.jl:10, called at
+ * src/quadrature.jl:109-110).  The reference has no FFI of its own for this path (its only
+ * foreign hop is FINUFFT.jl -> libfinufft); a Julia maintainer binds these symbols with
+ * `ccall` -- see INTEGRATION.md and spectralkernels.jl_amd/julia/SpectralKernelsHIP.jl.
+ *
+ * Conventions: plain pointers and sizes; all floating point is IEEE double; every function
+ * returns an sk_status (0 = OK); sk_last_error() gives the message the reference would have
+ * thrown.  A config handle owns its device buffers and is NOT re-entrant (the reference's
+ * config shares mutable scratch too, src/adaptive.jl:17-21).  The library owns all device
+ * memory except in the *_device entry, which takes HBM-resident arrays.
+ */
+#ifndef SPECTRALKERNELS_HIP_H
+#define SPECTRALKERNELS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  SK_OK = 0,
+  SK_EINVAL = 1,       /* ctor checks: criteria, alpha >= dim, p <= -1 (src/adaptive.jl:29-35, src/quadrature.jl:40) */
+  SK_ESUBDIVIDE = 2,   /* "(sub)interval split too many times (b - a < 1e-16)" (src/utils.jl:28-36) */
+  SK_ENAN = 3,         /* "NaN detected in panel integral" (src/quadrature.jl:165) */
+  SK_ESTACK = 4,       /* splitting stack capacity 5000 exceeded (src/quadrature.jl:7-15) */
+  SK_EHIP = 5,         /* HIP / rocFFT runtime failure */
+  SK_ENODEVICE = 6,    /* no gfx950 device visible: the product path has no CPU fallback */
+  SK_EUNSUPPORTED = 7, /* option outside the implemented scope (logw, dim > 2) */
+  SK_WARN_QUADSPEC = 100 /* tol < 1e-12 shrank quadspec to (2^12, 1) (src/adaptive.jl:37-40); config is valid */
+} sk_status;
+
+/* SDF catalogue evaluated on the device.  SK_SDF_CALLBACK evaluates a host closure in
+ * batches on the caller's thread (one batch of 3*m*k nodes per (sub)panel). */
+typedef enum {
+  SK_SDF_CALLBACK = 0,
+  SK_SDF_MATERN = 1,      /* params {phi, rho, nu, d}: phi*(rho^2+w^2)^(-nu-d/2)   scripts/matern_pair.jl:17 */
+  SK_SDF_EXPONENTIAL = 2, /* params {a}: exp(-a*|w|)                            test/exponential_sdf_1d.jl:3 */
+  SK_SDF_GAUSSIAN = 3     /* params {a}: exp(-(w/a)^2)  (super-algebraic tail -> :panel fallback) */
+} sk_sdf_kind;
+
+typedef enum { SK_CRIT_BOTH = 0, SK_CRIT_PANEL = 1, SK_CRIT_TAILS = 2 } sk_criteria;
+
+/* Batched SDF callback: out[i] = S(w[i]), i < n.  Called only on the thread that called
+ * sk_kernel_values / sk_compute_k0. */
+typedef void (*sk_sdf_batch_fn)(const double* w, double* out, size_t n, void* ctx);
+
+/* Keyword arguments of AdaptiveKernelConfig (src/adaptive.jl:24-27), same meaning. */
+typedef struct {
+  int sdf_kind;            /* sk_sdf_kind */
+  double sdf_params[8];
+  sk_sdf_batch_fn f;       /* used iff sdf_kind == SK_SDF_CALLBACK */
+  void* f_ctx;
+  sk_sdf_batch_fn df;      /* derivative of the SDF; only needed for logw (unsupported yet) */
+  void* df_ctx;
+  int dim;                 /* 1 (cos/sin kernel); even dims go through the Bessel path */
+  double alpha;            /* |w|^-alpha singularity at the origin */
+  double tol;              /* relative to K(0) */
+  int derivative;          /* K'(r) */
+  int logw;
+  int criteria;            /* sk_criteria */
+  int has_tail;
+  double tail;             /* power-law exponent override */
+  int64_t m, k;            /* quadspec: k sub-panels of m (and 2m) Gauss nodes per NUFFT */
+  int device;              /* HIP device ordinal; -1 = current device */
+  int nufft_width;         /* 0 = choose from tol; else spreading width w in [4,16] */
+} sk_config_args;
+
+typedef struct sk_config sk_config; /* opaque */
+
+/* Fills the defaults of src/adaptive.jl:24-27: dim=1, alpha=0, tol=1e-8, :both, quadspec=(4096,16). */
+void sk_config_args_default(sk_config_args* args);
+
+/* AdaptiveKernelConfig(...) -- src/adaptive.jl:24-59.  Returns SK_WARN_QUADSPEC with a valid
+ * handle when the tol<1e-12 rule applies. */
+int sk_config_create(sk_config** out, const sk_config_args* args);
+void sk_config_destroy(sk_config* cfg);
+
+/* Read back derived constants (src/adaptive.jl:42-45): p, c, effective (m,k). */
+int sk_config_info(const sk_config* cfg, double* p, double* c, int64_t* m, int64_t* k, int* nufft_width);
+
+/* Copies the config's Gauss rules (QuadRule, src/quadrature.jl:27-47) to the caller:
+ * which = 0 Legendre, 1 Jacobi(0,p); no1/wt1 have m entries, no2/wt2 2m.  Host-only. */
+int sk_config_rules(const sk_config* cfg, int which, double* no1, double* wt1, double* no2, double* wt2);
+
+/* compute_k0(config) -- src/adaptive.jl:74-91.  Host quadrature (adaptive Gauss-Kronrod). */
+int sk_compute_k0(sk_config* cfg, double* k0);
+
+/* kernel_values(config, xs; k0, param_derivative) -- src/adaptive.jl:95-108.
+ * xs: host array, any order, duplicates allowed, entries >= 0.  vals/errs: caller-allocated
+ * host arrays of length n, input order; errs is NaN at xs == 0 (src/adaptive.jl:137-144).
+ * has_k0 == 0 computes k0 with sk_compute_k0 first. */
+int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int has_k0, int param_derivative,
+                     double* vals_out, double* errs_out);
+
+/* Same computation on HBM-resident arrays: d_xs, d_vals, d_errs are device pointers on the
+ * config's device; stream is a hipStream_t (NULL = default stream).  Any order / duplicates
+ * allowed (device sort + dedup); already strictly increasing input skips that stage. The call
+ * returns after the results are complete on `stream` (it synchronises the stream). */
+int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double k0, int param_derivative,
+                            double* d_vals, double* d_errs, void* stream);
+
+/* finufft1d3-level seam (src/utils.jl:10; src/quadrature.jl:109-110): for real coefficients
+ * out_re/out_im[i] = sum_j coef[j] * exp(2*pi*i * nodes[j] * xs[i]).  Host pointers.
+ * method: 0 = type-3 NUFFT kernels (nodes must lie in [lo, hi], xs >= 0), 1 = direct-sum kernel. */
+int sk_panel_sums(sk_config* cfg, const double* nodes, const double* coef, size_t M, double lo, double hi,
+                  const double* xs, size_t n, int method, double* out_re, double* out_im);
+
+/* Statistics of the last sk_kernel_values* call on this config (panel schedule). */
+typedef struct {
+  int64_t n_unique;      /* targets after dedup */
+  int64_t n_outer;       /* outer panels marched (src/adaptive.jl:149 loop iterations) */
+  int64_t n_panels;      /* (sub)panel evaluations = NUFFT pairs Q */
+  int64_t n_accepted;
+  int64_t sum_active;    /* sum over panel evaluations of active targets (a-bar * N) */
+  int64_t n_steps_launched; /* device steps enqueued incl. speculative ones */
+  int64_t n_syncs;       /* host<->device synchronisations */
+  double last_b;         /* upper end of the last panel */
+} sk_stats;
+int sk_last_stats(const sk_config* cfg, sk_stats* out);
+
+/* Up to `cap` (a, b, max_err, n_active, accepted) records of the last call, in evaluation order.
+ * rec is cap x 5 doubles, row-major.  Returns the number of records written in *len. */
+int sk_last_trace(const sk_config* cfg, double* rec, size_t cap, size_t* len);
+
+/* Host-only hooks (no device needed) used by the CPU test tier: the config's Gauss rule
+ * generator (counterpart of FastGaussQuadrature at src/quadrature.jl:37-42), compute_k0 on the
+ * host (src/adaptive.jl:74-91), constructor validation (src/adaptive.jl:29-40) and the ES
+ * spreading kernel: closed form phi(z) and the piecewise-polynomial value used on the device. */
+int sk_host_gauss_rule(int64_t n, double p, double* nodes, double* weights);
+int sk_host_compute_k0(const sk_config_args* args, double* k0);
+int sk_host_validate(const sk_config_args* args, int64_t* m, int64_t* k);
+int sk_host_es_eval(int w, double z, double* phi, double* phi_poly);
+
+const char* sk_last_error(void);
+const char* sk_version(void);
+/* 1 iff a gfx950 device is usable by this process. */
+int sk_device_available(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

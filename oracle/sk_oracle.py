@@ -166,18 +166,46 @@ class AdaptiveKernelConfig:
 _RULE_CACHE = {}
 
 
+def _jacobi_eval_ld(n, b, x):
+    """P_n^{(0,b)}(x) and derivative by the three-term recurrence in long double (vectorised)."""
+    ld = np.longdouble
+    x = x.astype(ld)
+    b = ld(b)
+    p0 = np.ones_like(x)
+    p1 = ((b + 2) * x - b) / 2
+    for k in range(2, n + 1):
+        kk = ld(k)
+        s = 2 * kk + b
+        c1 = 2 * kk * (kk + b) * (s - 2)
+        c2 = (s - 1) * (s * (s - 2) * x - b * b)
+        c3 = 2 * (kk - 1) * (kk + b - 1) * s
+        p0, p1 = p1, (c2 * p1 - c3 * p0) / c1
+    nn = ld(n)
+    s = 2 * nn + b
+    dp = (nn * (-b - s * x) * p1 + 2 * nn * (nn + b) * p0) / (s * (1 - x * x))
+    return p1, dp
+
+
 def gauss_rules(m, p):
     """QuadRule (src/quadrature.jl:35-47): (no1, wt1, no2, wt2) for m and 2m nodes;
-    gausslegendre for p == 0, gaussjacobi(n, 0.0, p) otherwise (scipy equivalents)."""
+    gausslegendre for p == 0, gaussjacobi(n, 0.0, p) otherwise.  scipy supplies the nodes;
+    scipy's weights lose up to 6 digits at the panel ends for n ~ 10^4, so nodes are
+    Newton-polished and weights recomputed from w = 2^(p+1)/((1-x^2) P_n'(x)^2) in long double."""
     key = (int(m), float(p))
     if key not in _RULE_CACHE:
         out = []
         for n in (m, 2 * m):
             if p == 0.0:
-                x, w = special.roots_legendre(n)
+                x, _ = special.roots_legendre(n)
             else:
-                x, w = special.roots_jacobi(n, 0.0, p)
-            out += [np.ascontiguousarray(x), np.ascontiguousarray(w)]
+                x, _ = special.roots_jacobi(n, 0.0, p)
+            x = x.astype(np.longdouble)
+            for _ in range(2):
+                pn, dp = _jacobi_eval_ld(n, p, x)
+                x = x - pn / dp
+            pn, dp = _jacobi_eval_ld(n, p, x)
+            w = np.longdouble(2.0) ** np.longdouble(p + 1) / ((1 - x * x) * dp * dp)
+            out += [np.ascontiguousarray(x.astype(np.float64)), np.ascontiguousarray(w.astype(np.float64))]
         _RULE_CACHE[key] = tuple(out)
     return _RULE_CACHE[key]
 

@@ -1,0 +1,6 @@
+"""MI355X-native kernel_values hot path of SpectralKernels.jl (HIP kernels behind a C ABI)."""
+from .api import (SDF, AdaptiveKernelConfig, SpectralKernelsError, compute_k0, device_available, kernel_values,
+                  kernel_values_device, panel_sums)
+
+__all__ = ["SDF", "AdaptiveKernelConfig", "SpectralKernelsError", "compute_k0", "kernel_values",
+           "kernel_values_device", "panel_sums", "device_available"]

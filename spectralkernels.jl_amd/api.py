@@ -1,0 +1,191 @@
+"""Host-side mirror of the reference's exported API for the kernel_values path
+(src/SpectralKernels.jl:12): AdaptiveKernelConfig, compute_k0, kernel_values.
+
+Same keyword names, defaults, argument meaning and error behaviour as
+src/adaptive.jl:24-27 and :95-98; every computation goes through the C ABI
+(include/spectralkernels_hip.h) into the HIP library -- there is no Python or CPU
+compute path here.
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib as L
+
+
+class SpectralKernelsError(RuntimeError):
+    """Raised where the reference would `error(...)`."""
+
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class SDF:
+    """Spectral density: a device-catalogue entry or a host callable (evaluated in batches)."""
+
+    def __init__(self, kind, params=(), fn=None):
+        self.kind, self.params, self.fn = kind, tuple(float(p) for p in params), fn
+
+    @staticmethod
+    def matern(phi, rho, nu, d=1):
+        """phi*(rho^2+w^2)^(-nu-d/2)  (scripts/matern_pair.jl:17)"""
+        return SDF(L.SDF_MATERN, (phi, rho, nu, d))
+
+    @staticmethod
+    def exponential(a=1.0):
+        """exp(-a|w|)  (test/exponential_sdf_1d.jl:3)"""
+        return SDF(L.SDF_EXPONENTIAL, (a,))
+
+    @staticmethod
+    def gaussian(a=1.0):
+        return SDF(L.SDF_GAUSSIAN, (a,))
+
+    @staticmethod
+    def callback(fn):
+        """fn: vectorised callable ndarray -> ndarray (falls back to elementwise)."""
+        return SDF(L.SDF_CALLBACK, (), fn)
+
+
+_CRIT = {"both": 0, "panel": 1, "tails": 2}
+
+
+def _check(code):
+    if code not in (L.SK_OK, L.SK_WARN_QUADSPEC):
+        raise SpectralKernelsError(code, L.last_error())
+    return code
+
+
+def _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, tail, quadspec, device, nufft_width):
+    if not isinstance(f, SDF):
+        f = SDF.callback(f)
+    if convergence_criteria not in _CRIT:
+        raise SpectralKernelsError(L.SK_EINVAL, "Argument convergence_criteria must be one of :panel, :tails, :both.")
+    a = L.ConfigArgs()
+    L.load().sk_config_args_default(C.byref(a))
+    a.sdf_kind = f.kind
+    for i in range(8):
+        a.sdf_params[i] = f.params[i] if i < len(f.params) else 0.0
+    keep = None
+    if f.kind == L.SDF_CALLBACK:
+        fn = f.fn
+
+        def _batch(wp, outp, n, ctx):
+            w = np.ctypeslib.as_array(wp, shape=(n,))
+            out = np.ctypeslib.as_array(outp, shape=(n,))
+            try:
+                v = np.asarray(fn(w), dtype=np.float64)
+                if v.shape != (n,):
+                    raise ValueError
+            except Exception:
+                v = np.array([float(fn(float(x))) for x in w])
+            out[:] = v
+
+        keep = L.SDF_BATCH_FN(_batch)
+        a.f = keep
+    a.dim, a.alpha, a.tol = int(dim), float(alpha), float(tol)
+    a.derivative, a.logw = int(bool(derivative)), int(bool(logw))
+    a.criteria = _CRIT[convergence_criteria]
+    a.has_tail, a.tail = (0, 0.0) if tail is None else (1, float(tail))
+    a.m, a.k = int(quadspec[0]), int(quadspec[1])
+    a.device = int(device)
+    a.nufft_width = int(nufft_width)
+    return a, keep, f
+
+
+class AdaptiveKernelConfig:
+    """AdaptiveKernelConfig(f; df, dim, alpha, tol, derivative, logw, convergence_criteria, tail,
+    quadspec) -- src/adaptive.jl:24-59.  Owns a device-side config handle."""
+
+    def __init__(self, f, df=None, dim=1, alpha=0.0, tol=1e-8, derivative=False, logw=False,
+                 convergence_criteria="both", tail=None, quadspec=(2 ** 12, 2 ** 4), device=-1, nufft_width=0):
+        self._h = None
+        lib = L.load()
+        args, self._keep, self.f = _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, tail,
+                                              quadspec, device, nufft_width)
+        self._args = args
+        h = C.c_void_p()
+        code = _check(lib.sk_config_create(C.byref(h), C.byref(args)))
+        if code == L.SK_WARN_QUADSPEC:  # src/adaptive.jl:38
+            warnings.warn(L.last_error())
+        self._h = h
+        p, c = C.c_double(), C.c_double()
+        m, k, w = C.c_int64(), C.c_int64(), C.c_int()
+        lib.sk_config_info(h, C.byref(p), C.byref(c), C.byref(m), C.byref(k), C.byref(w))
+        self.p, self.c, self.quadspec, self.nufft_width = p.value, c.value, (m.value, k.value), w.value
+        self.dim, self.alpha, self.tol = int(dim), float(alpha), float(tol)
+        self.derivative, self.logw = bool(derivative), bool(logw)
+        self.convergence_criteria, self.tail = convergence_criteria, tail
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            L.load().sk_config_destroy(self._h)
+            self._h = None
+
+    def rules(self, which="legendre"):
+        """(no1, wt1, no2, wt2) of the config's QuadRule (src/quadrature.jl:27-47)."""
+        m = self.quadspec[0]
+        out = [np.zeros(m), np.zeros(m), np.zeros(2 * m), np.zeros(2 * m)]
+        _check(L.load().sk_config_rules(self._h, 0 if which == "legendre" else 1,
+                                        *[o.ctypes.data_as(C.c_void_p) for o in out]))
+        return tuple(out)
+
+    def last_stats(self):
+        s = L.Stats()
+        _check(L.load().sk_last_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in L.Stats._fields_}
+
+    def last_trace(self):
+        rec = np.zeros((4096, 5))
+        n = C.c_size_t()
+        _check(L.load().sk_last_trace(self._h, rec.ctypes.data_as(C.c_void_p), 4096, C.byref(n)))
+        return [dict(a=r[0], b=r[1], max_err=r[2], n_active=int(r[3]), accepted=bool(r[4])) for r in rec[:n.value]]
+
+
+def compute_k0(config):
+    """compute_k0(config) -- src/adaptive.jl:74-91."""
+    k0 = C.c_double()
+    _check(L.load().sk_compute_k0(config._h, C.byref(k0)))
+    return k0.value
+
+
+def kernel_values(config, xs, k0=None, param_derivative=False, verbose=False):
+    """kernel_values(config, xs; k0, param_derivative, verbose) -> (vals, errs)
+    src/adaptive.jl:95-108.  xs: host array (any order, duplicates allowed)."""
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    n = xs.size
+    vals, errs = np.zeros(n), np.zeros(n)
+    _check(L.load().sk_kernel_values(config._h, xs.ctypes.data_as(C.c_void_p), n, 0.0 if k0 is None else float(k0),
+                                     0 if k0 is None else 1, int(bool(param_derivative)),
+                                     vals.ctypes.data_as(C.c_void_p), errs.ctypes.data_as(C.c_void_p)))
+    if verbose:
+        st = config.last_stats()
+        print("Reducing %d to %d unique lags for evaluation..." % (n, st["n_unique"]))
+        for r in config.last_trace():
+            print("\tsubpanel w in [%.2e, %.2e] %s with max error %.2e (%d lags)" % (
+                r["a"], r["b"], "converged" if r["accepted"] else "did not converge", r["max_err"], r["n_active"]))
+    return vals, errs
+
+
+def kernel_values_device(config, d_xs_ptr, n, k0, d_vals_ptr, d_errs_ptr, param_derivative=False, stream_ptr=0):
+    """Device-resident variant: raw HBM pointers (e.g. torch.Tensor.data_ptr()) on the config's device."""
+    _check(L.load().sk_kernel_values_device(config._h, C.c_void_p(d_xs_ptr), int(n), float(k0),
+                                            int(bool(param_derivative)), C.c_void_p(d_vals_ptr),
+                                            C.c_void_p(d_errs_ptr), C.c_void_p(stream_ptr)))
+
+
+def panel_sums(config, nodes, coef, lo, hi, xs, method="nufft"):
+    """finufft1d3(nodes, coef, xs) (src/utils.jl:10): sum_j coef_j exp(2 pi i nodes_j xs_i) on the device."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    coef = np.ascontiguousarray(coef, dtype=np.float64)
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    re, im = np.zeros(xs.size), np.zeros(xs.size)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    _check(L.load().sk_panel_sums(config._h, p(nodes), p(coef), nodes.size, float(lo), float(hi), p(xs), xs.size,
+                                  1 if method == "direct" else 0, p(re), p(im)))
+    return re + 1j * im
+
+
+def device_available():
+    return bool(L.load().sk_device_available())

@@ -1,0 +1,720 @@
+// sk_api.cpp -- C ABI (include/spectralkernels_hip.h), config construction and the host driver
+// of the device-resident panel march.  Host-side mirror of src/adaptive.jl:24-108.
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "sk_device.h"
+#include "sk_internal.h"
+
+namespace sk {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return fail(SK_EHIP, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);        \
+  } while (0)
+#define FFTCHK(expr)                                                                       \
+  do {                                                                                     \
+    rocfft_status s_ = (expr);                                                             \
+    if (s_ != rocfft_status_success)                                                       \
+      return fail(SK_EHIP, std::string("rocFFT error ") + std::to_string((int)s_) + " at " #expr); \
+  } while (0)
+
+static std::once_flag g_fft_once;
+
+static int64_t next_smooth_even(int64_t n) {
+  if (n < 2) n = 2;
+  for (int64_t v = n + (n & 1);; v += 2) {
+    int64_t t = v;
+    for (int p : {2, 3, 5, 7})
+      while (t % p == 0) t /= p;
+    if (t == 1) return v;
+  }
+}
+
+}  // namespace sk
+
+using namespace sk;
+
+struct sk_config {
+  sk_config_args args;
+  int64_t m, k, M;
+  double p, c;
+  int device;
+  int warned;
+  SdfHost sdf;
+  // host rules
+  std::vector<double> leg[4], jac[4];
+  EsTables tab;
+  // device
+  DevConst dc;
+  DevBuffers db;
+  std::vector<void*> owned;  // device allocations freed at destroy
+  rocfft_plan plan = nullptr;
+  rocfft_execution_info info = nullptr;
+  void* fft_work = nullptr;
+  double* d_fvals = nullptr;
+  // per-call workspace (grow only)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  DevState* h_state = nullptr;  // pinned
+  int* d_flags = nullptr;
+  int* h_flags = nullptr;
+  long long* h_nuniq = nullptr;
+  hipStream_t own_stream = nullptr;
+  // last call
+  sk_stats stats;
+  std::vector<TraceRec> trace;
+  // callback scratch
+  std::vector<double> h_nodes, h_fvals;
+};
+
+namespace sk {
+
+template <class T>
+static int upload(sk_config* cfg, const std::vector<T>& v, const T** out) {
+  void* d = nullptr;
+  size_t bytes = v.size() * sizeof(T);
+  HIPCHK(hipMalloc(&d, bytes ? bytes : 8));
+  cfg->owned.push_back(d);
+  if (bytes) HIPCHK(hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice));
+  *out = (const T*)d;
+  return SK_OK;
+}
+
+template <class T>
+static int dalloc(sk_config* cfg, size_t count, T** out) {
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, count * sizeof(T) ? count * sizeof(T) : 8));
+  cfg->owned.push_back(d);
+  *out = (T*)d;
+  return SK_OK;
+}
+
+static int validate(const sk_config_args& a, int64_t& m, int64_t& k, int& warned) {
+  if (a.criteria < 0 || a.criteria > 2)
+    return fail(SK_EINVAL, "Argument convergence_criteria must be one of :panel, :tails, :both.");
+  if (a.dim < 1) return fail(SK_EINVAL, "dim must be >= 1");
+  if (a.alpha >= a.dim) return fail(SK_EINVAL, "alpha must be less than dim to be integrable.");
+  if (a.m < 1 || a.k < 1) return fail(SK_EINVAL, "quadspec entries must be positive");
+  if (!(a.tol > 0)) return fail(SK_EINVAL, "tol must be positive");
+  m = a.m;
+  k = a.k;
+  warned = 0;
+  if (a.tol < 1e-12 && m * k > 4096) {  // src/adaptive.jl:37-40
+    warned = 1;
+    m = 4096;
+    k = 1;
+  }
+  double p = -a.alpha + (a.dim == 1 ? 0.0 : a.dim / 2.0) + (a.derivative ? 1.0 : 0.0);
+  if (p != 0.0 && p <= -1.0) return fail(SK_EINVAL, "p needs to be in (-1.0, Inf) to be integrable");
+  if (a.sdf_kind == SK_SDF_CALLBACK && !a.f) return fail(SK_EINVAL, "sdf callback is null");
+  if (a.sdf_kind < 0 || a.sdf_kind > SK_SDF_GAUSSIAN) return fail(SK_EINVAL, "unknown sdf_kind");
+  return SK_OK;
+}
+
+static int choose_width(const sk_config_args& a) {
+  if (a.nufft_width) {
+    int w = a.nufft_width;
+    w = w < 4 ? 4 : (w > 16 ? 16 : w);
+    return w + (w & 1);
+  }
+  // NUFFT error target = tol/1000 (the reference always asks FINUFFT for 1e-15); w = digits + 1
+  double eps = std::fmax(a.tol * 1e-3, 1e-15);
+  int w = (int)std::ceil(-std::log10(eps)) + 1;
+  w += (w & 1);
+  return w < 4 ? 4 : (w > 16 ? 16 : w);
+}
+
+// composite-rule source positions in grid units for one variant/rule, plus cell starts
+static void build_positions(const sk_config* cfg, int variant, int rule, std::vector<double>& pos,
+                            std::vector<int>& cellstart) {
+  const int64_t m = cfg->m, k = cfg->k, n1 = cfg->dc.n1;
+  const int64_t mr = rule ? 2 * m : m;
+  const std::vector<double>& leg = cfg->leg[rule ? 2 : 0];
+  const std::vector<double>& jac = cfg->jac[rule ? 2 : 0];
+  pos.resize((size_t)(mr * k));
+  const long double delta = 2.0L / (long double)(n1 - cfg->dc.w);
+  for (int64_t sp = 0; sp < k; ++sp)
+    for (int64_t q = 0; q < mr; ++q) {
+      long double t = (variant == 1 && sp == 0) ? (long double)jac[q] : (long double)leg[q];
+      long double u = ((2.0L * sp + 1.0L) / (long double)k - 1.0L) + t / (long double)k;
+      pos[(size_t)(sp * mr + q)] = (double)(u / delta + 0.5L * (long double)n1);
+    }
+  cellstart.assign((size_t)n1 + 1, 0);
+  std::vector<int> cnt((size_t)n1 + 1, 0);
+  for (double P : pos) {
+    int64_t cidx = (int64_t)std::floor(P);
+    cidx = cidx < 0 ? 0 : (cidx >= n1 ? n1 - 1 : cidx);
+    cnt[(size_t)cidx + 1]++;
+  }
+  for (int64_t i = 0; i < n1; ++i) cellstart[(size_t)i + 1] = cellstart[(size_t)i] + cnt[(size_t)i + 1];
+}
+
+static int ensure_ws(sk_config* cfg, size_t bytes) {
+  if (bytes <= cfg->ws_bytes) return SK_OK;
+  if (cfg->ws) HIPCHK(hipFree(cfg->ws));
+  cfg->ws = nullptr;
+  cfg->ws_bytes = 0;
+  size_t want = bytes + bytes / 4;
+  HIPCHK(hipMalloc(&cfg->ws, want));
+  cfg->ws_bytes = want;
+  return SK_OK;
+}
+
+static const char* status_message(int code) {
+  switch (code) {
+    case SK_ESUBDIVIDE:
+      return "The sub-interval (a, b) has been split too many times (b - a < 1e-16). Exiting to avoid infinite splitting.";
+    case SK_ENAN: return "NaN detected in panel integral...";
+    case SK_ESTACK: return "splitting stack capacity (5000) exceeded";
+    default: return "device-side failure";
+  }
+}
+
+// host nodes of the current (sub)panel for callback SDFs (same arithmetic as k_gen)
+static void host_nodes(const sk_config* cfg, const PanelParams& pp, std::vector<double>& w) {
+  const int64_t m = cfg->m, k = cfg->k, M = cfg->M;
+  w.resize((size_t)(3 * M));
+  for (int rule = 0; rule < 2; ++rule) {
+    const int64_t mr = rule ? 2 * m : m;
+    const std::vector<double>& no = (rule ? cfg->leg[2] : cfg->leg[0]);
+    const std::vector<double>& jno = (rule ? cfg->jac[2] : cfg->jac[0]);
+    double* out = w.data() + (rule ? M : 0);
+    for (int64_t sp = 0; sp < k; ++sp) {
+      double sa = (sp == 0) ? pp.pa : pp.pa + (pp.pb - pp.pa) * ((double)sp / (double)k);
+      double sb = (sp + 1 == k) ? pp.pb : pp.pa + (pp.pb - pp.pa) * ((double)(sp + 1) / (double)k);
+      double bmad2 = 0.5 * (sb - sa), bpad2 = 0.5 * (sb + sa);
+      const std::vector<double>& nn = (pp.jacobi && sp == 0) ? jno : no;
+      for (int64_t q = 0; q < mr; ++q) out[sp * mr + q] = bmad2 * nn[q] + bpad2;
+    }
+  }
+}
+
+static int run_fft(sk_config* cfg, hipStream_t st) {
+  FFTCHK(rocfft_execution_info_set_stream(cfg->info, st));
+  void* in[1] = {cfg->db.fft};
+  FFTCHK(rocfft_execute(cfg->plan, in, nullptr, cfg->info));
+  return SK_OK;
+}
+
+// core march on sorted unique lags already on the device (src/adaptive.jl:110-202)
+static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0, double ks0, double* d_ks, double* d_errs,
+                    double* d_scratch4n, hipStream_t st) {
+  DevBuffers& db = cfg->db;
+  db.xs = d_uxs;
+  db.ks = d_ks;
+  db.errs = d_errs;
+  db.P = d_scratch4n;
+  db.E = db.P + n;
+  db.tmpI = db.E + n;
+  db.tmpE = db.tmpI + n;
+  db.fvals = cfg->d_fvals;
+  HIPCHK(hipMemsetAsync(d_ks, 0, sizeof(double) * n, st));
+  HIPCHK(hipMemsetAsync(d_errs, 0, sizeof(double) * n, st));
+  HIPCHK(hipMemsetAsync(db.P, 0, sizeof(double) * 2 * n, st));
+  launch_init(cfg->dc, db, n, k0, ks0, st);
+  const bool cb = (cfg->dc.sdf_kind == SK_SDF_CALLBACK);
+  int slot = 0;
+  int R = cb ? 1 : 2;
+  sk_stats& stt = cfg->stats;
+  DevState* hs = cfg->h_state;
+  for (;;) {
+    if (cb) {
+      HIPCHK(hipMemcpyAsync(hs, &db.state[slot], sizeof(DevState), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      stt.n_syncs++;
+      if (hs->done) break;
+      host_nodes(cfg, hs->pp, cfg->h_nodes);
+      cfg->h_fvals.resize(cfg->h_nodes.size());
+      cfg->sdf.batch(cfg->h_nodes.data(), cfg->h_fvals.data(), cfg->h_nodes.size());
+      HIPCHK(hipMemcpyAsync(cfg->d_fvals, cfg->h_fvals.data(), sizeof(double) * cfg->h_fvals.size(),
+                            hipMemcpyHostToDevice, st));
+      double fb = cfg->sdf(hs->b);
+      HIPCHK(hipMemcpyAsync(&db.state[slot].fb, &fb, sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    for (int r = 0; r < R; ++r) {
+      launch_gen(cfg->dc, db, slot, st);
+      launch_spread(cfg->dc, db, slot, st);
+      int rc = run_fft(cfg, st);
+      if (rc) return rc;
+      launch_interp(cfg->dc, db, slot, n, st);
+      launch_accum(cfg->dc, db, slot, n, st);
+      launch_advance(cfg->dc, db, slot, st);
+      slot ^= 1;
+      stt.n_steps_launched++;
+    }
+    if (!cb) {
+      HIPCHK(hipMemcpyAsync(hs, &db.state[slot], sizeof(DevState), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      stt.n_syncs++;
+      if (hs->done) break;
+      R = R < 16 ? 2 * R : 16;
+    }
+  }
+  launch_final(cfg->dc, db, slot, n, st);
+  HIPCHK(hipGetLastError());
+  // stats + trace
+  stt.n_outer = hs->n_outer;
+  stt.n_panels = hs->n_panels;
+  stt.n_accepted = hs->n_accepted;
+  stt.sum_active = hs->sum_active;
+  stt.last_b = hs->b;
+  cfg->trace.resize((size_t)hs->trace_len);
+  if (hs->trace_len)
+    HIPCHK(hipMemcpyAsync(cfg->trace.data(), db.trace, sizeof(TraceRec) * hs->trace_len, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (hs->done < 0) return fail(-hs->done, status_message(-hs->done));
+  return SK_OK;
+}
+
+static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t n, double k0, double ks0, double* d_vals,
+                                     double* d_errs, hipStream_t st) {
+  std::memset(&cfg->stats, 0, sizeof(cfg->stats));
+  cfg->trace.clear();
+  if (n == 0) return SK_OK;
+  HIPCHK(hipSetDevice(cfg->device));
+  HIPCHK(hipMemsetAsync(cfg->d_flags, 0, 2 * sizeof(int), st));
+  launch_check_sorted(d_xs, (long long)n, cfg->d_flags, st);
+  HIPCHK(hipMemcpyAsync(cfg->h_flags, cfg->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  cfg->stats.n_syncs++;
+  if (cfg->h_flags[1]) return fail(SK_EINVAL, "lags must be non-negative and finite");
+  const size_t a8 = ((n * 8 + 255) / 256) * 256;
+  if (!cfg->h_flags[0]) {
+    // strictly increasing: outputs double as accumulators
+    int rc = ensure_ws(cfg, 4 * a8);
+    if (rc) return rc;
+    cfg->stats.n_unique = (int64_t)n;
+    return run_core(cfg, d_xs, (long long)n, k0, ks0, d_vals, d_errs, (double*)cfg->ws, st);
+  }
+  // src/adaptive.jl:99-120: unique + sort, then gather back
+  const size_t tb = sort_unique_temp_bytes((long long)n);
+  int rc = ensure_ws(cfg, 8 * a8 + tb + 256);
+  if (rc) return rc;
+  char* base = (char*)cfg->ws;
+  double* uxs = (double*)base; base += a8;
+  long long* inv = (long long*)base; base += a8;
+  double* ks = (double*)base; base += a8;
+  double* errs = (double*)base; base += a8;
+  double* scr = (double*)base; base += 4 * a8;
+  long long* d_nu = (long long*)base; base += 256;
+  sort_unique(d_xs, (long long)n, uxs, inv, d_nu, base, tb, st);
+  HIPCHK(hipMemcpyAsync(cfg->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  cfg->stats.n_syncs++;
+  const long long nu = *cfg->h_nuniq;
+  cfg->stats.n_unique = nu;
+  rc = run_core(cfg, uxs, nu, k0, ks0, ks, errs, scr, st);
+  if (rc) return rc;
+  launch_gather(ks, errs, inv, (long long)n, d_vals, d_errs, st);
+  HIPCHK(hipStreamSynchronize(st));
+  return SK_OK;
+}
+
+}  // namespace sk
+
+// ====================================================================== C ABI
+
+extern "C" {
+
+const char* sk_last_error(void) { return g_err.c_str(); }
+const char* sk_version(void) { return "spectralkernels_hip 0.1.0 (gfx950)"; }
+
+int sk_device_available(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+  return std::strstr(prop.gcnArchName, "gfx950") != nullptr ? 1 : 0;
+}
+
+void sk_config_args_default(sk_config_args* a) {
+  std::memset(a, 0, sizeof(*a));
+  a->sdf_kind = SK_SDF_MATERN;
+  a->sdf_params[0] = 1.0;
+  a->sdf_params[1] = 1.0;
+  a->sdf_params[2] = 1.5;
+  a->sdf_params[3] = 1.0;
+  a->dim = 1;
+  a->alpha = 0.0;
+  a->tol = 1e-8;
+  a->criteria = SK_CRIT_BOTH;
+  a->m = 4096;
+  a->k = 16;
+  a->device = -1;
+}
+
+int sk_config_create(sk_config** out, const sk_config_args* args) {
+  if (!out || !args) return fail(SK_EINVAL, "null argument");
+  *out = nullptr;
+  int64_t m, k;
+  int warned;
+  int rc = validate(*args, m, k, warned);
+  if (rc) return rc;
+  if (args->logw) return fail(SK_EUNSUPPORTED, "logw=true is not implemented on the HIP path yet");
+  if (args->dim != 1) return fail(SK_EUNSUPPORTED, "dim > 1 (Hankel path) is not implemented on the HIP path yet");
+  if (!sk_device_available())
+    return fail(SK_ENODEVICE, "no gfx950 device available: the HIP path has no CPU fallback");
+  int dev = args->device;
+  if (dev < 0) {
+    if (hipGetDevice(&dev) != hipSuccess) return fail(SK_EHIP, "hipGetDevice failed");
+  }
+  HIPCHK(hipSetDevice(dev));
+  sk_config* cfg = new sk_config();
+  cfg->args = *args;
+  cfg->m = m;
+  cfg->k = k;
+  cfg->M = m * k;
+  cfg->device = dev;
+  cfg->warned = warned;
+  cfg->p = -args->alpha + (args->dim == 1 ? 0.0 : args->dim / 2.0) + (args->derivative ? 1.0 : 0.0);
+  cfg->c = (args->dim == 1 ? 2.0 : 2.0 * M_PI) * (args->derivative ? -2.0 * M_PI : 1.0) * (args->logw ? -1.0 : 1.0);
+  cfg->sdf.kind = args->sdf_kind;
+  std::memcpy(cfg->sdf.prm, args->sdf_params, sizeof(cfg->sdf.prm));
+  cfg->sdf.f = args->f;
+  cfg->sdf.ctx = args->f_ctx;
+  std::memset(&cfg->stats, 0, sizeof(cfg->stats));
+  // rules (src/adaptive.jl:47-49)
+  gauss_rule(m, 0.0, cfg->leg[0], cfg->leg[1]);
+  gauss_rule(2 * m, 0.0, cfg->leg[2], cfg->leg[3]);
+  if (cfg->p != 0.0) {
+    gauss_rule(m, cfg->p, cfg->jac[0], cfg->jac[1]);
+    gauss_rule(2 * m, cfg->p, cfg->jac[2], cfg->jac[3]);
+    if (cfg->jac[0].empty() || cfg->jac[2].empty()) {
+      delete cfg;
+      return fail(SK_EINVAL, "Gauss-Jacobi rule generation failed");
+    }
+  } else {
+    for (int i = 0; i < 4; ++i) cfg->jac[i] = cfg->leg[i];
+  }
+  // NUFFT geometry
+  DevConst& dc = cfg->dc;
+  std::memset(&dc, 0, sizeof(dc));
+  dc.m = m; dc.k = k; dc.M = cfg->M;
+  dc.dim = args->dim; dc.derivative = args->derivative; dc.crit0 = args->criteria; dc.has_tail = args->has_tail;
+  dc.alpha = args->alpha; dc.p = cfg->p; dc.c = cfg->c; dc.tol = args->tol; dc.tail = args->tail;
+  dc.sdf_kind = args->sdf_kind;
+  std::memcpy(dc.sdf_prm, args->sdf_params, sizeof(dc.sdf_prm));
+  dc.w = choose_width(*args);
+  {
+    int64_t need = (int64_t)std::ceil(0.99 * (double)cfg->M) + dc.w;
+    int64_t n1 = cfg->M >= need && (cfg->M % 2 == 0) ? cfg->M : need;
+    if (n1 < 4 * dc.w) n1 = 4 * dc.w;
+    dc.n1 = next_smooth_even(n1);
+    dc.n2 = 2 * dc.n1;
+  }
+  dc.delta = 2.0 / (double)(dc.n1 - dc.w);
+  dc.theta_max = 1.001 * (M_PI / 2.0) * (double)cfg->M / (double)(dc.n1 - dc.w);
+  build_es_tables(dc.w, dc.n1, dc.n2, dc.theta_max, cfg->tab);
+  dc.nco = cfg->tab.nco;
+  dc.ncheb = cfg->tab.ncheb;
+#define UP(vec, field)                                     \
+  do {                                                     \
+    rc = upload(cfg, vec, &field);                         \
+    if (rc) { sk_config_destroy(cfg); return rc; }         \
+  } while (0)
+  UP(cfg->leg[0], dc.leg_no1); UP(cfg->leg[1], dc.leg_wt1); UP(cfg->leg[2], dc.leg_no2); UP(cfg->leg[3], dc.leg_wt2);
+  UP(cfg->jac[0], dc.jac_no1); UP(cfg->jac[1], dc.jac_wt1); UP(cfg->jac[2], dc.jac_no2); UP(cfg->jac[3], dc.jac_wt2);
+  UP(cfg->tab.poly, dc.poly); UP(cfg->tab.cheb, dc.cheb); UP(cfg->tab.deconv, dc.deconv);
+  for (int variant = 0; variant < 2; ++variant)
+    for (int rule = 0; rule < 2; ++rule) {
+      if (variant == 1 && cfg->p == 0.0) {
+        dc.pos[1][rule] = dc.pos[0][rule];
+        dc.cellstart[1][rule] = dc.cellstart[0][rule];
+        continue;
+      }
+      std::vector<double> pos;
+      std::vector<int> cs;
+      build_positions(cfg, variant, rule, pos, cs);
+      UP(pos, dc.pos[variant][rule]);
+      UP(cs, dc.cellstart[variant][rule]);
+    }
+#undef UP
+  DevBuffers& db = cfg->db;
+  std::memset(&db, 0, sizeof(db));
+#define DA(count, field)                                   \
+  do {                                                     \
+    rc = dalloc(cfg, count, &field);                       \
+    if (rc) { sk_config_destroy(cfg); return rc; }         \
+  } while (0)
+  DA(2, db.state); DA(kStackCap, db.stack); DA(kTraceCap, db.trace);
+  DA((size_t)cfg->M, db.src1); DA((size_t)2 * cfg->M, db.src2); DA((size_t)2 * dc.n2, db.fft);
+  DA((size_t)3 * cfg->M, cfg->d_fvals);
+  DA(2, cfg->d_flags);
+#undef DA
+  if (hipHostMalloc((void**)&cfg->h_state, sizeof(DevState)) != hipSuccess ||
+      hipHostMalloc((void**)&cfg->h_flags, 2 * sizeof(int)) != hipSuccess ||
+      hipHostMalloc((void**)&cfg->h_nuniq, sizeof(long long)) != hipSuccess) {
+    sk_config_destroy(cfg);
+    return fail(SK_EHIP, "hipHostMalloc failed");
+  }
+  if (hipStreamCreate(&cfg->own_stream) != hipSuccess) {
+    sk_config_destroy(cfg);
+    return fail(SK_EHIP, "hipStreamCreate failed");
+  }
+  // rocFFT plan: length n2, batch 2 (m-rule and 2m-rule), in place, e^{+i...}
+  std::call_once(g_fft_once, [] { rocfft_setup(); });
+  size_t len[1] = {(size_t)dc.n2};
+  rocfft_status fs = rocfft_plan_create(&cfg->plan, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+                                        rocfft_precision_double, 1, len, 2, nullptr);
+  if (fs != rocfft_status_success) {
+    sk_config_destroy(cfg);
+    return fail(SK_EHIP, "rocfft_plan_create failed");
+  }
+  size_t wb = 0;
+  rocfft_plan_get_work_buffer_size(cfg->plan, &wb);
+  rocfft_execution_info_create(&cfg->info);
+  if (wb) {
+    if (hipMalloc(&cfg->fft_work, wb) != hipSuccess) {
+      sk_config_destroy(cfg);
+      return fail(SK_EHIP, "hipMalloc(fft work) failed");
+    }
+    rocfft_execution_info_set_work_buffer(cfg->info, cfg->fft_work, wb);
+  }
+  *out = cfg;
+  if (warned) {
+    set_error(
+        "Tolerances < 1e-12 are not recommended. Switching to a smaller quadrature rule for higher accuracy (but "
+        "slower) computations.");
+    return SK_WARN_QUADSPEC;
+  }
+  return SK_OK;
+}
+
+void sk_config_destroy(sk_config* cfg) {
+  if (!cfg) return;
+  hipSetDevice(cfg->device);
+  if (cfg->plan) rocfft_plan_destroy(cfg->plan);
+  if (cfg->info) rocfft_execution_info_destroy(cfg->info);
+  if (cfg->fft_work) hipFree(cfg->fft_work);
+  for (void* p : cfg->owned) hipFree(p);
+  if (cfg->ws) hipFree(cfg->ws);
+  if (cfg->h_state) hipHostFree(cfg->h_state);
+  if (cfg->h_flags) hipHostFree(cfg->h_flags);
+  if (cfg->h_nuniq) hipHostFree(cfg->h_nuniq);
+  if (cfg->own_stream) hipStreamDestroy(cfg->own_stream);
+  delete cfg;
+}
+
+int sk_config_info(const sk_config* cfg, double* p, double* c, int64_t* m, int64_t* k, int* nufft_width) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  if (p) *p = cfg->p;
+  if (c) *c = cfg->c;
+  if (m) *m = cfg->m;
+  if (k) *k = cfg->k;
+  if (nufft_width) *nufft_width = cfg->dc.w;
+  return SK_OK;
+}
+
+int sk_config_rules(const sk_config* cfg, int which, double* no1, double* wt1, double* no2, double* wt2) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  const std::vector<double>* r = which ? cfg->jac : cfg->leg;
+  if (no1) std::memcpy(no1, r[0].data(), r[0].size() * 8);
+  if (wt1) std::memcpy(wt1, r[1].data(), r[1].size() * 8);
+  if (no2) std::memcpy(no2, r[2].data(), r[2].size() * 8);
+  if (wt2) std::memcpy(wt2, r[3].data(), r[3].size() * 8);
+  return SK_OK;
+}
+
+int sk_compute_k0(sk_config* cfg, double* k0) {
+  if (!cfg || !k0) return fail(SK_EINVAL, "null argument");
+  *k0 = compute_k0_host(cfg->sdf, cfg->args.dim, cfg->p, cfg->c, cfg->args.derivative, cfg->args.logw, cfg->args.tol);
+  return SK_OK;
+}
+
+int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double k0, int param_derivative, double* d_vals,
+                            double* d_errs, void* stream) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  double ks0 = k0;  // src/adaptive.jl:134-145
+  if (cfg->args.derivative) ks0 = 0.0;
+  else if (param_derivative) {
+    int rc = sk_compute_k0(cfg, &ks0);
+    if (rc) return rc;
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : cfg->own_stream;
+  return kernel_values_device_impl(cfg, d_xs, n, k0, ks0, d_vals, d_errs, st);
+}
+
+int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int has_k0, int param_derivative,
+                     double* vals_out, double* errs_out) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  if (!has_k0) {
+    int rc = sk_compute_k0(cfg, &k0);
+    if (rc) return rc;
+  }
+  if (n == 0) return SK_OK;
+  HIPCHK(hipSetDevice(cfg->device));
+  double* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 3 * n * sizeof(double)));
+  hipStream_t st = cfg->own_stream;
+  int rc = SK_OK;
+  if (hipMemcpyAsync(d, xs, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+    rc = fail(SK_EHIP, "H2D copy failed");
+  if (!rc) rc = sk_kernel_values_device(cfg, d, n, k0, param_derivative, d + n, d + 2 * n, st);
+  if (!rc) {
+    if (hipMemcpyAsync(vals_out, d + n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(errs_out, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      rc = fail(SK_EHIP, "D2H copy failed");
+  }
+  hipFree(d);
+  return rc;
+}
+
+int sk_panel_sums(sk_config* cfg, const double* nodes, const double* coef, size_t M, double lo, double hi,
+                  const double* xs, size_t n, int method, double* out_re, double* out_im) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  if (n == 0) return SK_OK;
+  HIPCHK(hipSetDevice(cfg->device));
+  hipStream_t st = cfg->own_stream;
+  double *d_nodes = nullptr, *d_coef = nullptr, *d_xs = nullptr, *d_re = nullptr, *d_im = nullptr;
+  HIPCHK(hipMalloc((void**)&d_nodes, (2 * M + 3 * n + 8) * sizeof(double)));
+  d_coef = d_nodes + M;
+  d_xs = d_coef + M;
+  d_re = d_xs + n;
+  d_im = d_re + n;
+  int rc = SK_OK;
+  auto done = [&](int code) {
+    hipFree(d_nodes);
+    return code;
+  };
+  if (hipMemcpyAsync(d_nodes, nodes, M * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_coef, coef, M * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_xs, xs, n * 8, hipMemcpyHostToDevice, st) != hipSuccess)
+    return done(fail(SK_EHIP, "H2D copy failed"));
+  if (method == 1) {
+    launch_direct(d_nodes, d_coef, (int64_t)M, d_xs, (int64_t)n, d_re, d_im, st);
+  } else {
+    double r_hi = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+      if (!(xs[i] >= 0.0)) return done(fail(SK_EINVAL, "lags must be non-negative"));
+      r_hi = std::fmax(r_hi, xs[i]);
+    }
+    if (!(hi > lo)) return done(fail(SK_EINVAL, "need hi > lo"));
+    for (size_t j = 0; j < M; ++j)
+      if (!(nodes[j] >= lo && nodes[j] <= hi)) return done(fail(SK_EINVAL, "nodes must lie in [lo, hi]"));
+    if (r_hi == 0.0) r_hi = 1.0;
+    const DevConst& dc = cfg->dc;
+    const double Cx = 0.5 * (lo + hi), X = 0.5 * (hi - lo);
+    const double xr = X * r_hi;
+    if (xr > 0.25 * (double)cfg->M * (1.0 + 1e-9))
+      return done(fail(SK_EINVAL, "space-bandwidth product (hi-lo)/2*max(xs) exceeds m*k/4 of this config"));
+    const double kappa = 0.5 * xr, tau = xr * (double)dc.n2 / (double)(dc.n1 - dc.w);
+    const double theta_scale = 2.0 * M_PI * xr / (double)(dc.n1 - dc.w);
+    if (hipMemsetAsync(cfg->db.fft, 0, sizeof(double2) * 2 * dc.n2, st) != hipSuccess)
+      return done(fail(SK_EHIP, "memset failed"));
+    launch_seam_spread(dc, d_nodes, d_coef, (int64_t)M, Cx, X, kappa, cfg->db.fft, st);
+    launch_seam_deconv(dc, cfg->db.fft, st);
+    rc = run_fft(cfg, st);
+    if (rc) return done(rc);
+    launch_seam_interp(dc, cfg->db.fft, d_xs, (int64_t)n, Cx, r_hi, tau, theta_scale, d_re, d_im, st);
+  }
+  if (hipMemcpyAsync(out_re, d_re, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(out_im, d_im, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return done(fail(SK_EHIP, "D2H copy failed"));
+  if (hipGetLastError() != hipSuccess) return done(fail(SK_EHIP, "kernel launch failed"));
+  return done(SK_OK);
+}
+
+int sk_last_stats(const sk_config* cfg, sk_stats* out) {
+  if (!cfg || !out) return fail(SK_EINVAL, "null argument");
+  *out = cfg->stats;
+  return SK_OK;
+}
+
+int sk_last_trace(const sk_config* cfg, double* rec, size_t cap, size_t* len) {
+  if (!cfg || !len) return fail(SK_EINVAL, "null argument");
+  size_t nrec = cfg->trace.size() < cap ? cfg->trace.size() : cap;
+  for (size_t i = 0; i < nrec; ++i) {
+    const TraceRec& r = cfg->trace[i];
+    rec[5 * i + 0] = r.a;
+    rec[5 * i + 1] = r.b;
+    rec[5 * i + 2] = r.max_err;
+    rec[5 * i + 3] = r.n_active;
+    rec[5 * i + 4] = r.accepted;
+  }
+  *len = nrec;
+  return SK_OK;
+}
+
+// host-only hooks (no device needed): used by the CPU test tier
+int sk_host_gauss_rule(int64_t n, double p, double* nodes, double* weights) {
+  std::vector<double> x, w;
+  gauss_rule(n, p, x, w);
+  if ((int64_t)x.size() != n) return fail(SK_EINVAL, "rule generation failed");
+  std::memcpy(nodes, x.data(), n * 8);
+  std::memcpy(weights, w.data(), n * 8);
+  return SK_OK;
+}
+
+int sk_host_compute_k0(const sk_config_args* a, double* k0) {
+  if (!a || !k0) return fail(SK_EINVAL, "null argument");
+  int64_t m, k;
+  int warned;
+  int rc = validate(*a, m, k, warned);
+  if (rc) return rc;
+  SdfHost f;
+  f.kind = a->sdf_kind;
+  std::memcpy(f.prm, a->sdf_params, sizeof(f.prm));
+  f.f = a->f;
+  f.ctx = a->f_ctx;
+  double p = -a->alpha + (a->dim == 1 ? 0.0 : a->dim / 2.0) + (a->derivative ? 1.0 : 0.0);
+  double c = (a->dim == 1 ? 2.0 : 2.0 * M_PI) * (a->derivative ? -2.0 * M_PI : 1.0) * (a->logw ? -1.0 : 1.0);
+  *k0 = compute_k0_host(f, a->dim, p, c, a->derivative, a->logw, a->tol);
+  return SK_OK;
+}
+
+int sk_host_validate(const sk_config_args* a, int64_t* m, int64_t* k) {
+  if (!a) return fail(SK_EINVAL, "null argument");
+  int64_t mm, kk;
+  int warned;
+  int rc = validate(*a, mm, kk, warned);
+  if (rc) return rc;
+  if (m) *m = mm;
+  if (k) *k = kk;
+  return warned ? SK_WARN_QUADSPEC : SK_OK;
+}
+
+// ES-kernel tables for host tests: phi(z), phi_hat(xi) and the piecewise polynomial value.
+int sk_host_es_eval(int w, double z, double* phi, double* phi_poly) {
+  static thread_local EsTables t;
+  static thread_local int tw = 0;
+  if (tw != w) {
+    build_es_tables(w, 64, 128, 1.6, t);
+    tw = w;
+  }
+  if (phi) *phi = es_phi(z, w, t.beta);
+  if (phi_poly) {
+    double zq = z + 0.5 * w;
+    int q = (int)std::floor(zq);
+    q = q < 0 ? 0 : (q > w - 1 ? w - 1 : q);
+    double y = zq - q - 0.5;
+    int qq = q < w / 2 ? q : w - 1 - q;
+    const double* pe = &t.poly[(size_t)qq * 2 * t.nco];
+    const double* po = pe + t.nco;
+    double E = pe[0], O = po[0];
+    for (int i = 1; i < t.nco; ++i) {
+      E = E * y * y + pe[i];
+      O = O * y * y + po[i];
+    }
+    *phi_poly = (q < w / 2) ? E + y * O : E - y * O;
+  }
+  return SK_OK;
+}
+
+}  // extern "C"

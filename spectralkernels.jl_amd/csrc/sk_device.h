@@ -1,0 +1,103 @@
+// sk_device.h -- device-resident state of the adaptive panel march and kernel launch API.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace sk {
+
+constexpr int kMaxWidth = 16;
+constexpr int kMaxNco = kMaxWidth / 2 + 2;
+constexpr int kMaxCheb = 24;
+constexpr int kStackCap = 5000;  // src/quadrature.jl:7
+constexpr int kTraceCap = 4096;
+
+// Per-config constants, passed to kernels by value.
+struct DevConst {
+  // quadrature
+  int64_t m, k, M;     // quadspec and M = m*k
+  int dim, derivative, crit0, has_tail;
+  double alpha, p, c, tol, tail;
+  int sdf_kind;        // 0 = values supplied by host callback
+  double sdf_prm[8];
+  // NUFFT geometry (fixed per config): spread grid n1, FFT length n2, width w
+  int64_t n1, n2;
+  int w, nco, ncheb;
+  double theta_max, delta;  // delta = 2/(n1-w): grid spacing in u = (omega-Cx)/X
+  // tables (device pointers)
+  const double* leg_no1; const double* leg_wt1; const double* leg_no2; const double* leg_wt2;
+  const double* jac_no1; const double* jac_wt1; const double* jac_no2; const double* jac_wt2;
+  const double* pos[2][2];      // [variant][rule] source positions in grid units, P_j in [w/2, n1-w/2]
+  const int* cellstart[2][2];   // [variant][rule] first source with floor(P_j) >= cell, n1+1 entries
+  const double* poly;           // (w/2) x 2 x nco piecewise-polynomial coefficients
+  const double* cheb;           // ncheb Chebyshev coefficients of 1/phi_hat
+  const double* deconv;         // n1/2+1 values of 1/phi_hat(2 pi l/n2)
+};
+
+struct PanelParams {
+  double pa, pb;        // current (sub)panel
+  double Cx, X;         // centre, half-width
+  double r_hi;          // largest active lag
+  double kappa;         // X * r_hi/2: pre-phase turns per unit u
+  double tau;           // fine-grid position of target: t = tau * v, v = 2 r / r_hi - 1
+  double theta_scale;   // theta = theta_scale * v
+  int jacobi;           // Gauss-Jacobi rule on the first sub-panel (p != 0 and pa == 0)
+};
+
+struct DevState {
+  PanelParams pp;
+  double a, b;          // outer panel (src/adaptive.jl:152)
+  double fb;            // S(b) for the tail fit (src/adaptive.jl:204-220)
+  double k0abs;         // |k0|
+  double ks0;           // value stored at x == 0
+  long long n, ix1, hi, hi_prev;  // active lags are [ix1, hi)
+  int crit, done, stack_len, retire_pending;
+  unsigned long long max_err_bits;  // atomicMax over the bit pattern of |I2-I1| >= 0
+  unsigned long long hi_new;        // atomicMax over i+1 of unconverged lags
+  int nan1, nan2;
+  long long n_outer, n_panels, n_accepted, sum_active;
+  int trace_len;
+};
+
+struct TraceRec { double a, b, max_err, n_active, accepted; };
+
+struct DevBuffers {
+  DevState* state;          // 2 slots (ping-pong)
+  double2* stack;           // kStackCap (a,b) pairs
+  TraceRec* trace;          // kTraceCap
+  double2* src1; double2* src2;   // pre-phased coefficients, M and 2M
+  double2* fft;             // 2 x n2 complex (rule 1, rule 2)
+  const double* fvals;      // callback mode: S(omega_j) for rule 1 (M) then rule 2 (2M)
+  const double* xs;         // sorted unique lags
+  double* ks; double* errs; // accumulators (output, sorted-unique order)
+  double* P; double* E;     // outer-panel partial sums
+  double* tmpI; double* tmpE;
+};
+
+// launchers (sk_kernels.hip)
+void launch_init(const DevConst& dc, const DevBuffers& db, long long n, double k0, double ks0, hipStream_t st);
+void launch_gen(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);
+void launch_spread(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);
+void launch_interp(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st);
+void launch_accum(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st);
+void launch_advance(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);
+void launch_final(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st);
+
+// seam kernels for sk_panel_sums
+void launch_seam_spread(const DevConst& dc, const double* nodes, const double* coef, int64_t M, double Cx, double X,
+                        double kappa, double2* fft, hipStream_t st);
+void launch_seam_deconv(const DevConst& dc, double2* fft, hipStream_t st);
+void launch_seam_interp(const DevConst& dc, const double2* fft, const double* xs, int64_t n, double Cx, double r_hi,
+                        double tau, double theta_scale, double* out_re, double* out_im, hipStream_t st);
+void launch_direct(const double* nodes, const double* coef, int64_t M, const double* xs, int64_t n, double* out_re,
+                   double* out_im, hipStream_t st);
+
+// sort / dedup helpers
+void launch_check_sorted(const double* xs, long long n, int* flags, hipStream_t st);  // flags[0]=not strictly increasing, flags[1]=invalid (<0 or NaN)
+size_t sort_unique_temp_bytes(long long n);
+// returns number of unique values in *n_unique (device int64) and fills uxs, inv
+void sort_unique(const double* xs, long long n, double* uxs, long long* inv, long long* d_n_unique, void* temp,
+                 size_t temp_bytes, hipStream_t st);
+void launch_gather(const double* ks, const double* errs, const long long* inv, long long n, double* vals, double* errs_out,
+                   hipStream_t st);
+
+}  // namespace sk
