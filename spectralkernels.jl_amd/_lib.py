@@ -26,6 +26,13 @@ class Stats(C.Structure):
                 ("last_b", C.c_double)]
 
 
+K_NAMES = ["gen", "spread", "fft", "interp", "accum", "advance"]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("total_ms", C.c_double * 6), ("launches", C.c_int64 * 6), ("active_items", C.c_int64 * 6)]
+
+
 _lib = None
 
 
@@ -53,6 +60,8 @@ def load():
     L.sk_panel_sums.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_double, vp, C.c_size_t, C.c_int, vp, vp]
     L.sk_last_stats.argtypes = [vp, C.POINTER(Stats)]
     L.sk_last_trace.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sk_profile_enable.argtypes = [vp, C.c_int]
+    L.sk_profile_read.argtypes = [vp, C.POINTER(KernelTimes)]
     L.sk_host_gauss_rule.argtypes = [C.c_int64, C.c_double, vp, vp]
     L.sk_host_compute_k0.argtypes = [C.POINTER(ConfigArgs), dp]
     L.sk_host_validate.argtypes = [C.POINTER(ConfigArgs), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]

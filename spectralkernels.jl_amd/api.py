@@ -136,6 +136,17 @@ class AdaptiveKernelConfig:
         _check(L.load().sk_last_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in L.Stats._fields_}
 
+    def profile(self, on=True):
+        """Bracket every kernel launch of the following calls with HIP events (see kernel_times)."""
+        _check(L.load().sk_profile_enable(self._h, int(bool(on))))
+
+    def kernel_times(self):
+        """{kernel: dict(total_ms, launches, active_items)} of the last profiled call."""
+        kt = L.KernelTimes()
+        _check(L.load().sk_profile_read(self._h, C.byref(kt)))
+        return {name: dict(total_ms=kt.total_ms[i], launches=kt.launches[i], active_items=kt.active_items[i])
+                for i, name in enumerate(L.K_NAMES)}
+
     def last_trace(self):
         rec = np.zeros((4096, 5))
         n = C.c_size_t()

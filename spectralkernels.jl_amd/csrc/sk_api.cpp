@@ -80,6 +80,13 @@ struct sk_config {
   std::vector<TraceRec> trace;
   // callback scratch
   std::vector<double> h_nodes, h_fvals;
+  // optional per-kernel event timing
+  int profile = 0;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  struct EvRec { int kid; hipEvent_t a, b; };
+  std::vector<EvRec> ev_recs;
+  sk_kernel_times ktimes;
 };
 
 namespace sk {
@@ -204,6 +211,34 @@ static void host_nodes(const sk_config* cfg, const PanelParams& pp, std::vector<
   }
 }
 
+static hipEvent_t ev_get(sk_config* cfg) {
+  if (cfg->ev_used == cfg->ev_pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    cfg->ev_pool.push_back(e);
+  }
+  return cfg->ev_pool[cfg->ev_used++];
+}
+struct EvScope {
+  sk_config* cfg;
+  hipStream_t st;
+  int kid;
+  hipEvent_t a, b;
+  EvScope(sk_config* c, hipStream_t s, int k) : cfg(c), st(s), kid(k) {
+    if (cfg->profile) {
+      a = ev_get(cfg);
+      b = ev_get(cfg);
+      (void)hipEventRecord(a, st);
+    }
+  }
+  ~EvScope() {
+    if (cfg->profile) {
+      (void)hipEventRecord(b, st);
+      cfg->ev_recs.push_back({kid, a, b});
+    }
+  }
+};
+
 static int run_fft(sk_config* cfg, hipStream_t st) {
   FFTCHK(rocfft_execution_info_set_stream(cfg->info, st));
   void* in[1] = {cfg->db.fft};
@@ -247,13 +282,16 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       HIPCHK(hipMemcpyAsync(&db.state[slot].fb, &fb, sizeof(double), hipMemcpyHostToDevice, st));
     }
     for (int r = 0; r < R; ++r) {
-      launch_gen(cfg->dc, db, slot, st);
-      launch_spread(cfg->dc, db, slot, st);
-      int rc = run_fft(cfg, st);
-      if (rc) return rc;
-      launch_interp(cfg->dc, db, slot, n, st);
-      launch_accum(cfg->dc, db, slot, n, st);
-      launch_advance(cfg->dc, db, slot, st);
+      { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, slot, st); }
+      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, db, slot, st); }
+      {
+        EvScope e(cfg, st, SK_K_FFT);
+        int rc = run_fft(cfg, st);
+        if (rc) return rc;
+      }
+      { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, db, slot, n, st); }
+      { EvScope e(cfg, st, SK_K_ACCUM); launch_accum(cfg->dc, db, slot, n, st); }
+      { EvScope e(cfg, st, SK_K_ADVANCE); launch_advance(cfg->dc, db, slot, st); }
       slot ^= 1;
       stt.n_steps_launched++;
     }
@@ -277,6 +315,27 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   if (hs->trace_len)
     HIPCHK(hipMemcpyAsync(cfg->trace.data(), db.trace, sizeof(TraceRec) * hs->trace_len, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if (cfg->profile) {
+    std::memset(&cfg->ktimes, 0, sizeof(cfg->ktimes));
+    // only the first n_panels steps did work; later (speculative) steps exit early
+    int64_t seen[SK_K_COUNT] = {0};
+    for (auto& r : cfg->ev_recs) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, r.a, r.b);
+      if (seen[r.kid]++ < hs->n_panels) {
+        cfg->ktimes.total_ms[r.kid] += ms;
+        cfg->ktimes.launches[r.kid] += 1;
+      }
+    }
+    cfg->ktimes.active_items[SK_K_GEN] = 3 * cfg->M * hs->n_panels;
+    cfg->ktimes.active_items[SK_K_SPREAD] = 2 * cfg->dc.n2 * hs->n_panels;
+    cfg->ktimes.active_items[SK_K_FFT] = 2 * cfg->dc.n2 * hs->n_panels;
+    cfg->ktimes.active_items[SK_K_INTERP] = hs->sum_active;
+    cfg->ktimes.active_items[SK_K_ACCUM] = hs->sum_active;
+    cfg->ktimes.active_items[SK_K_ADVANCE] = hs->n_panels;
+    cfg->ev_recs.clear();
+    cfg->ev_used = 0;
+  }
   if (hs->done < 0) return fail(-hs->done, status_message(-hs->done));
   return SK_OK;
 }
@@ -507,6 +566,7 @@ void sk_config_destroy(sk_config* cfg) {
   if (cfg->h_flags) hipHostFree(cfg->h_flags);
   if (cfg->h_nuniq) hipHostFree(cfg->h_nuniq);
   if (cfg->own_stream) hipStreamDestroy(cfg->own_stream);
+  for (hipEvent_t e : cfg->ev_pool) hipEventDestroy(e);
   delete cfg;
 }
 
@@ -629,6 +689,18 @@ int sk_panel_sums(sk_config* cfg, const double* nodes, const double* coef, size_
     return done(fail(SK_EHIP, "D2H copy failed"));
   if (hipGetLastError() != hipSuccess) return done(fail(SK_EHIP, "kernel launch failed"));
   return done(SK_OK);
+}
+
+int sk_profile_enable(sk_config* cfg, int on) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  cfg->profile = on ? 1 : 0;
+  return SK_OK;
+}
+
+int sk_profile_read(const sk_config* cfg, sk_kernel_times* out) {
+  if (!cfg || !out) return fail(SK_EINVAL, "null argument");
+  *out = cfg->ktimes;
+  return SK_OK;
 }
 
 int sk_last_stats(const sk_config* cfg, sk_stats* out) {
