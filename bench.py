@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- r-targets/sec through kernel_values on MI355X (BASELINE.json metric).
+
+One "step" = one kernel_values pass over one batch of synthetic lags that are already resident
+in HBM (sk_kernel_values_device): BASELINE config 2 by default -- Matern nu=3/2 SDF
+S(w) = (1+w^2)^-2, 10^6 log-spaced r in [1e-6, 1], tol = 1e-8, quadspec (4096, 16).
+Multi-GPU: one process per GPU, every rank marches its own 10^6-lag shard of the r-set
+(weak scaling, no data-path collective); the only exchange is the K(0) normaliser, whose
+quadrature is split over the ranks and summed with one all-reduce (RCCL) at set-up.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (sdf kind, params, config kwargs, r-grid builder, k0, truth)
+    "C2": dict(desc="Matern nu=3/2 S=(1+w^2)^-2, 1e6 log-spaced r in [1e-6,1], tol=1e-8, quadspec=(4096,16)",
+               sdf=("matern", (1.0, 1.0, 1.5)), kw=dict(tol=1e-8), n=10 ** 6, lo=-6.0, hi=0.0),
+    "C3": dict(desc="singular long-memory SDF alpha=0.4 (rho=10, nu=0.5, K(0)=1), 1e6 log-spaced r in [1e-8,1e-2], "
+                    "tol=1e-8, quadspec=(256,16)",
+               sdf=("matern", None), kw=dict(tol=1e-8, alpha=0.4, quadspec=(256, 16)), n=10 ** 6, lo=-8.0, hi=-2.0),
+}
+
+
+def shard_grid(w, rank, world):
+    """Rank `rank` of `world` gets every world-th lag of the world*n log-spaced global grid."""
+    n = w["n"]
+    g = 10.0 ** np.linspace(w["lo"], w["hi"], n * world)
+    return np.ascontiguousarray(g[rank::world])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="lags in the CPU-baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import spectralkernels_jl_amd as sk
+    from spectralkernels_jl_amd import dist as skdist
+
+    w = WORKLOADS[args.workload]
+    kind, prm = w["sdf"]
+    if prm is None:  # C3: normalise K(0) = 1 with the closed form (scripts/singular_matern_demo.jl:21)
+        from scipy import special
+        q = (1 - 0.4) / 2
+        prm = (1.0 / (10.0 ** (1 - 0.4 - 2 * 1.0) * special.beta(q, 1.0 - q)), 10.0, 0.5)
+    cfg = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), **w["kw"])
+
+    # shared K(0) normaliser: quadrature split over ranks + one all-reduce (RCCL over xGMI)
+    k0 = skdist.shared_k0(cfg, dist, torch.device("cuda", local_rank))
+
+    rs = shard_grid(w, rank, world)
+    n = rs.size
+    d_rs = torch.from_numpy(rs).cuda()
+    d_ks = torch.empty_like(d_rs)
+    d_errs = torch.empty_like(d_rs)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        sk.kernel_values_device(cfg, d_rs.data_ptr(), n, k0, d_ks.data_ptr(), d_errs.data_ptr(), stream_ptr=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * n / (dt / args.steps)
+
+    # ---- accuracy of this rank's shard against the closed form
+    ks = d_ks.cpu().numpy()
+    st = cfg.last_stats()
+    if args.workload == "C2":
+        truth = k0 * (1 + 2 * np.pi * rs) * np.exp(-2 * np.pi * rs)
+        max_rel_err = float(np.abs(ks - truth).max() / abs(k0))
+    else:
+        max_rel_err = None
+
+    # ---- per-kernel roofline from HIP events on the kernels' own stream (separate, untimed passes)
+    cfg.profile(True)
+    acc = None
+    for _ in range(10):
+        step()
+        kt = cfg.kernel_times()
+        if acc is None:
+            acc = {k: dict(v) for k, v in kt.items()}
+        else:
+            for k in kt:
+                for f in ("total_ms", "launches", "active_items"):
+                    acc[k][f] += kt[k][f]
+    cfg.profile(False)
+    dom = max(acc, key=lambda k: acc[k]["total_ms"])
+    # algorithmic bytes per launch: interp/accum per active lag, gen/spread per panel
+    M = cfg.quadspec[0] * cfg.quadspec[1]
+    alg_bytes = {"interp": 24.0, "accum": 40.0}
+    rl = {}
+    for k, v in acc.items():
+        if v["launches"] == 0:
+            continue
+        avg_ms = v["total_ms"] / v["launches"]
+        items = v["active_items"] / v["launches"]
+        if k in alg_bytes:
+            b = alg_bytes[k] * items
+        elif k == "gen":
+            b = 48.0 * M  # nodes + real weights of both rules (M + 2M) x (8 + 8)
+        elif k == "spread":
+            b = 48.0 * M + 2 * 16.0 * (items / 2)  # read sources, write two complex grids
+        elif k == "fft":
+            b = 2 * 16.0 * items  # read + write both grids once
+        else:
+            b = 0.0
+        rl[k] = dict(avg_us=1e3 * avg_ms, bytes=b, gbps=(b / (avg_ms * 1e-3) / 1e9) if avg_ms > 0 else 0.0,
+                     launches_per_step=v["launches"] / 10.0)
+    peak = 8000.0
+    roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": rl[dom]["gbps"], "peak": peak, "unit": "GB/s",
+                "frac": rl[dom]["gbps"] / peak, "traffic": None, "avg_us": rl[dom]["avg_us"],
+                "per_kernel": {k: {"avg_us": round(v["avg_us"], 3), "GB/s": round(v["gbps"], 1),
+                                   "launches_per_step": v["launches_per_step"]} for k, v in rl.items()}}
+    # whole-step view: algorithmic bytes per lag (24 + 40*abar + 48*M*Q/N) over the step time
+    abar = st["sum_active"] / max(1, st["n_unique"])
+    bytes_per_lag = 24.0 + 40.0 * abar + 48.0 * M * st["n_panels"] / max(1, n)
+    roofline["step_GB/s"] = bytes_per_lag * n / (ms_per_step * 1e-3) / 1e9
+    roofline["step_frac"] = roofline["step_GB/s"] / peak
+    roofline["bytes_per_lag"] = bytes_per_lag
+
+    # ---- CPU baseline: the oracle (a port, not FINUFFT) on a bounded sample of the same workload
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import sk_oracle as o
+        ns = args.cpu_sample or (2000 if M > 10000 else 20000)
+        idx = np.unique(np.r_[np.linspace(0, n - 1, ns).astype(int), n - 1])
+        ocfg = o.AdaptiveKernelConfig(getattr(o.SDF, kind)(*prm), **w["kw"])
+        o.gauss_rules(ocfg.quadspec[0], ocfg.p)
+        tc = time.perf_counter()
+        oks, _ = o.kernel_values(ocfg, rs[idx], k0=k0)
+        tcpu = time.perf_counter() - tc
+        cpu = {"value": idx.size / tcpu, "unit": "r-targets/s", "cores": ocfg.nthreads, "kind": "port",
+               "sample": "%d of the %d lags (every ~%d-th, incl. the largest), exact direct sums in the oracle "
+                         "(no NUFFT); %.1f s" % (idx.size, n, n // idx.size, tcpu),
+               "max_abs_diff_vs_gpu_over_k0": float(np.abs(oks - ks[idx]).max() / abs(k0))}
+
+    if rank == 0:
+        out = {"metric": "r-targets/sec at tol=1e-8", "value": value, "unit": "r-targets/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": args.workload + ": " + w["desc"], "lags_per_gpu": n,
+                          "sharding": "r-set strided over ranks, K(0) all-reduce at set-up only",
+                          "nufft_width": cfg.nufft_width},
+               "max_rel_err_vs_closed_form": max_rel_err,
+               "panels": {"outer": st["n_outer"], "nufft_pairs": st["n_panels"], "abar": abar,
+                          "steps_launched": st["n_steps_launched"], "host_syncs": st["n_syncs"]},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,6 +150,9 @@ int sk_last_trace(const sk_config* cfg, double* rec, size_t cap, size_t* len);
  * spreading kernel: closed form phi(z) and the piecewise-polynomial value used on the device. */
 int sk_host_gauss_rule(int64_t n, double p, double* nodes, double* weights);
 int sk_host_compute_k0(const sk_config_args* args, double* k0);
+/* Partial K(0): the same integral restricted to the mapped variable t in [t_lo, t_hi) of [0,1),
+ * w = t/(1-t); the parts of a partition of [0,1) sum to sk_host_compute_k0 (multi-GPU set-up). */
+int sk_host_compute_k0_part(const sk_config_args* args, double t_lo, double t_hi, double* part);
 int sk_host_validate(const sk_config_args* args, int64_t* m, int64_t* k);
 int sk_host_es_eval(int w, double z, double* phi, double* phi_poly);
 

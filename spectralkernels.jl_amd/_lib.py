@@ -64,6 +64,7 @@ def load():
     L.sk_profile_read.argtypes = [vp, C.POINTER(KernelTimes)]
     L.sk_host_gauss_rule.argtypes = [C.c_int64, C.c_double, vp, vp]
     L.sk_host_compute_k0.argtypes = [C.POINTER(ConfigArgs), dp]
+    L.sk_host_compute_k0_part.argtypes = [C.POINTER(ConfigArgs), C.c_double, C.c_double, dp]
     L.sk_host_validate.argtypes = [C.POINTER(ConfigArgs), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sk_host_es_eval.argtypes = [C.c_int, C.c_double, dp, dp]
     L.sk_last_error.restype = C.c_char_p

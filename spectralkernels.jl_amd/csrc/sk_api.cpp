@@ -751,6 +751,24 @@ int sk_host_compute_k0(const sk_config_args* a, double* k0) {
   return SK_OK;
 }
 
+int sk_host_compute_k0_part(const sk_config_args* a, double t_lo, double t_hi, double* part) {
+  if (!a || !part) return fail(SK_EINVAL, "null argument");
+  int64_t m, k;
+  int warned;
+  int rc = validate(*a, m, k, warned);
+  if (rc) return rc;
+  if (!(t_lo >= 0.0 && t_hi <= 1.0 && t_lo < t_hi)) return fail(SK_EINVAL, "need 0 <= t_lo < t_hi <= 1");
+  SdfHost f;
+  f.kind = a->sdf_kind;
+  std::memcpy(f.prm, a->sdf_params, sizeof(f.prm));
+  f.f = a->f;
+  f.ctx = a->f_ctx;
+  double p = -a->alpha + (a->dim == 1 ? 0.0 : a->dim / 2.0) + (a->derivative ? 1.0 : 0.0);
+  double c = (a->dim == 1 ? 2.0 : 2.0 * M_PI) * (a->derivative ? -2.0 * M_PI : 1.0) * (a->logw ? -1.0 : 1.0);
+  *part = compute_k0_host(f, a->dim, p, c, a->derivative, a->logw, a->tol, t_lo, t_hi);
+  return SK_OK;
+}
+
 int sk_host_validate(const sk_config_args* a, int64_t* m, int64_t* k) {
   if (!a) return fail(SK_EINVAL, "null argument");
   int64_t mm, kk;

@@ -27,7 +27,8 @@ struct SdfHost {
 };
 
 // compute_k0 (src/adaptive.jl:74-91): adaptive Gauss-Kronrod on [0, inf).
-double compute_k0_host(const SdfHost& f, int dim, double p, double c, int derivative, int logw, double tol);
+double compute_k0_host(const SdfHost& f, int dim, double p, double c, int derivative, int logw, double tol,
+                       double t_lo = 0.0, double t_hi = 1.0);
 
 // ES ("exponential of semicircle") spreading kernel tables.
 struct EsTables {

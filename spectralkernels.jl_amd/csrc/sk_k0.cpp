@@ -73,7 +73,8 @@ Seg eval_seg(const F& g, double a, double b, long& nev) {
 }
 }  // namespace
 
-double compute_k0_host(const SdfHost& f, int dim, double p, double c, int derivative, int logw, double tol) {
+double compute_k0_host(const SdfHost& f, int dim, double p, double c, int derivative, int logw, double tol, double t_lo,
+                       double t_hi) {
   // src/adaptive.jl:77-80
   double L = 1.0;
   const double f0 = std::fabs(f(0.0));
@@ -96,7 +97,7 @@ double compute_k0_host(const SdfHost& f, int dim, double p, double c, int deriva
   const double rtol = std::fmin(1e-8, 1e-2 * tol);
   long nev = 0;
   std::priority_queue<Seg> heap;
-  Seg s0 = eval_seg(g, 0.0, 1.0, nev);
+  Seg s0 = eval_seg(g, t_lo, t_hi, nev);
   double I = s0.I, E = s0.E;
   heap.push(s0);
   const long maxev = 10000000;  // QuadGK default maxevals = 10^7

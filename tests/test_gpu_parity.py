@@ -1,0 +1,235 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures and against closed-form truths.
+
+Tolerance (north_star): results must match the reference CPU path within the user tol
+relative to K(0).  Here: |hip - oracle| <= 0.1*tol*K(0) when both follow the same panel
+schedule, and the reference tests' own acceptance |hip - truth| <= 10*tol*K(0)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def pair(sk, oracle, kind, prm, **kw):
+    mk = lambda mod: getattr(mod.SDF, kind)(*prm)
+    return sk.AdaptiveKernelConfig(mk(sk), **kw), oracle.AdaptiveKernelConfig(mk(oracle), **kw)
+
+
+def schedule(tr):
+    return [(r["a"], r["b"], bool(r["accepted"]), int(r["n_active"])) for r in tr]
+
+
+def check_pair(sk, oracle, cfg, ocfg, rs, k0, tol, same_schedule=True, **kv):
+    ks, errs = sk.kernel_values(cfg, rs, k0=k0, **kv)
+    oks, oerrs, otr = oracle.kernel_values(ocfg, rs, k0=k0, return_trace=True, **kv)
+    a0 = abs(k0)
+    assert np.array_equal(np.isnan(errs), np.isnan(oerrs))
+    d = np.nanmax(np.abs(ks - oks)) / a0
+    # 0.1*tol, floored at the accuracy of a width-16 NUFFT (the reference's FINUFFT call asks for
+    # 1e-15 and delivers ~1e-14..1e-13 relative to sum|c_j|)
+    assert d <= max(0.1 * tol, 5e-13), d
+    if same_schedule:
+        assert schedule(cfg.last_trace()) == schedule(otr)
+        de = np.nanmax(np.abs(errs - oerrs)) / a0
+        assert de <= max(0.1 * tol, 5e-13), de
+    return ks, errs
+
+
+def test_c1_readme_demo_against_fixture_and_oracle_schedule(sk):
+    # BASELINE config 1 (README.md:21-33), default quadspec; fixture made by the oracle
+    z = np.load(os.path.join(GOLD, "c1_matern32_default.npz"))
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5))
+    ks, errs = sk.kernel_values(cfg, z["rs"])  # k0 computed by the library
+    k0 = float(z["k0"])
+    assert np.abs(ks - z["ks"]).max() / k0 <= 1e-9
+    assert np.abs(ks - z["truth"]).max() / k0 <= 10 * 1e-8
+    assert np.abs(errs - z["errs"]).max() / k0 <= 1e-9
+    tr = cfg.last_trace()
+    assert [(r["a"], r["b"], r["accepted"]) for r in tr] == [(a, b, bool(acc)) for a, b, _, _, acc in z["trace"]]
+
+
+@pytest.mark.parametrize("name,kind,prm,kw", [
+    ("c2_matern32_small_rule_unsorted.npz", "matern", (1, 1, 1.5), dict(quadspec=(256, 16))),
+    ("exp_derivative.npz", "exponential", (1.0,), dict(derivative=True, quadspec=(256, 16))),
+    ("bisect_narrow_matern.npz", "matern", (1.0, 1e-3, 1.5), dict(quadspec=(64, 4))),
+])
+def test_fixtures(sk, name, kind, prm, kw):
+    z = np.load(os.path.join(GOLD, name))
+    cfg = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), **kw)
+    k0 = float(z["k0"])
+    ks, errs = sk.kernel_values(cfg, z["rs"], k0=k0)
+    assert np.nanmax(np.abs(ks - z["ks"])) / abs(k0) <= 1e-9
+    assert np.nanmax(np.abs(ks - z["truth"])) / abs(k0) <= 10 * 1e-8
+    assert np.array_equal(np.isnan(errs), np.isnan(z["errs"]))
+    tr = cfg.last_trace()
+    assert [(r["a"], r["b"], r["accepted"]) for r in tr] == [(a, b, bool(acc)) for a, b, _, _, acc in z["trace"]]
+
+
+def test_fixture_c3_singular(sk, oracle):
+    z = np.load(os.path.join(GOLD, "c3_singular_alpha04.npz"))
+    phi = 1.0 / oracle.sing_matern_k0(0.4, (1.0, 10.0, 0.5))
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(phi, 10.0, 0.5), alpha=0.4, quadspec=(256, 16))
+    ks, errs = sk.kernel_values(cfg, z["rs"], k0=1.0)
+    assert np.abs(ks - z["ks"]).max() <= 1e-9
+    assert np.abs(ks - z["truth"]).max() <= 10 * 1e-8
+    assert len(cfg.last_trace()) == z["trace"].shape[0]
+
+
+def test_fixture_c5_tol1e12(sk):
+    z = np.load(os.path.join(GOLD, "c5_matern_tol1e-12.npz"))
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(2.14, 0.97, 0.89), tol=1e-12, quadspec=(256, 16))
+    k0 = float(z["k0"])
+    ks, errs = sk.kernel_values(cfg, z["rs"], k0=k0)
+    assert cfg.nufft_width == 16
+    assert np.nanmax(np.abs(ks - z["truth"])) / k0 <= 10 * 1e-12  # test/matern_sdf.jl:27
+    assert np.nanmax(np.abs(ks - z["ks"])) / k0 <= 2e-12
+    assert np.isnan(errs[0]) and ks[0] == k0
+
+
+@pytest.mark.parametrize("tol", [1e-4, 1e-8, 1e-10, 1e-12])
+def test_tol_ladder_vs_oracle(sk, oracle, tol):
+    rng = np.random.default_rng(11)
+    rs = np.sort(rng.uniform(0.0, 5.1, 300))
+    parms = (2.14, 0.97, 0.89)
+    cfg, ocfg = pair(sk, oracle, "matern", parms, tol=tol, quadspec=(256, 16))
+    k0 = float(oracle.matern_cov(0.0, parms))
+    ks, _ = check_pair(sk, oracle, cfg, ocfg, rs, k0, tol, same_schedule=(tol >= 1e-10))
+    assert np.abs(ks - oracle.matern_cov(rs, parms)).max() / k0 <= 10 * tol
+
+
+def test_unsorted_duplicates_zero_edge_cases(sk, oracle):
+    # src/adaptive.jl:99-120, :132-146
+    rng = np.random.default_rng(3)
+    base = 10.0 ** rng.uniform(-5, 0, 200)
+    rs = np.concatenate([base, base[:50], [0.0, 0.0, -0.0], [base.max()] * 3])
+    rs = rs[rng.permutation(rs.size)]
+    cfg, ocfg = pair(sk, oracle, "matern", (1, 1, 1.5), quadspec=(256, 16))
+    ks, errs = check_pair(sk, oracle, cfg, ocfg, rs, np.pi / 2, 1e-8)
+    assert cfg.last_stats()["n_unique"] == 201
+    z = rs == 0
+    assert np.all(ks[z] == np.pi / 2) and np.all(np.isnan(errs[z])) and not np.any(np.isnan(errs[~z]))
+    # duplicates get identical values; order of the input is preserved
+    for v in base[:5]:
+        assert len(set(ks[rs == v])) == 1
+    # empty, single lag, only zeros
+    e = sk.kernel_values(cfg, np.zeros(0), k0=1.0)
+    assert e[0].size == 0 and e[1].size == 0
+    one, _ = sk.kernel_values(cfg, np.array([0.3]), k0=np.pi / 2)
+    assert abs(one[0] - np.pi / 2 * (1 + 0.6 * np.pi) * np.exp(-0.6 * np.pi)) <= 1e-8 * np.pi / 2
+    zs, ze = sk.kernel_values(cfg, np.zeros(4), k0=np.pi / 2)
+    assert np.all(zs == np.pi / 2) and np.all(np.isnan(ze))
+    with pytest.raises(sk.SpectralKernelsError):
+        sk.kernel_values(cfg, np.array([0.1, -0.2]), k0=1.0)
+    with pytest.raises(sk.SpectralKernelsError):
+        sk.kernel_values(cfg, np.array([0.1, np.nan]), k0=1.0)
+
+
+@pytest.mark.parametrize("alpha,quadspec", [(0.4, (256, 16)), (0.5, (64, 8)), (0.2, (256, 4))])
+def test_singular_sdf_jacobi_branch(sk, oracle, alpha, quadspec):
+    # src/quadrature.jl:61-78: Gauss-Jacobi on the first sub-panel when a == 0 and p != 0
+    parms = (2.14, 0.97, 0.89)
+    rs = np.linspace(0.0, 1.1, 150)
+    cfg, ocfg = pair(sk, oracle, "matern", parms, alpha=alpha, quadspec=quadspec)
+    k0 = oracle.sing_matern_k0(alpha, parms)
+    ks, _ = check_pair(sk, oracle, cfg, ocfg, rs, k0, 1e-8)
+    truth = oracle.sing_matern_cov(rs[1:], -alpha, parms)
+    assert np.abs(ks[1:] - truth).max() / k0 <= 10 * 1e-8
+    # the config's rules are the oracle's (scipy + long-double Newton) rules
+    for mine, theirs in zip(cfg.rules("jacobi"), ocfg.jac):
+        assert np.abs(mine - theirs).max() <= 1e-13 * max(1.0, np.abs(theirs).max())
+
+
+@pytest.mark.parametrize("criteria", ["both", "panel", "tails"])
+def test_convergence_criteria(sk, oracle, criteria):
+    rs = 10.0 ** np.linspace(-4, 0.5, 120)
+    cfg, ocfg = pair(sk, oracle, "matern", (1.0, 0.5, 0.55), convergence_criteria=criteria, quadspec=(256, 16))
+    k0 = float(oracle.matern_cov(0.0, (1.0, 0.5, 0.55)))
+    check_pair(sk, oracle, cfg, ocfg, rs, k0, 1e-8)
+
+
+def test_tail_override_and_panel_fallback(sk, oracle):
+    rs = 10.0 ** np.linspace(-3, 0.5, 100)
+    # user-supplied tail exponent (src/adaptive.jl:211)
+    cfg, ocfg = pair(sk, oracle, "matern", (1, 1, 1.5), tail=-4.0, quadspec=(256, 16))
+    check_pair(sk, oracle, cfg, ocfg, rs, np.pi / 2, 1e-8)
+    # Gaussian SDF underflows to 0 at b -> NaN tail fit -> :panel for the rest of the call (:170-175)
+    cfg, ocfg = pair(sk, oracle, "gaussian", (3.0,), quadspec=(256, 16))
+    k0 = 3.0 * np.sqrt(np.pi)
+    ks, _ = check_pair(sk, oracle, cfg, ocfg, rs, k0, 1e-8)
+    truth = k0 * np.exp(-(np.pi * 3.0 * rs) ** 2)
+    assert np.abs(ks - truth).max() / k0 <= 10 * 1e-8
+
+
+def test_derivative_and_param_derivative(sk, oracle):
+    rs = np.linspace(0.0, 5.1, 200)
+    cfg, ocfg = pair(sk, oracle, "exponential", (1.0,), derivative=True, quadspec=(256, 16))
+    ks, errs = check_pair(sk, oracle, cfg, ocfg, rs, 2.0, 1e-8)
+    assert ks[0] == 0.0 and np.isnan(errs[0])  # src/adaptive.jl:135-137
+    assert np.abs(ks - oracle.exponential_cov_deriv(rs)).max() / 2.0 <= 10 * 1e-8
+    # param_derivative: value at 0 is compute_k0(cfg), k0 only scales the tolerances (:138-141)
+    cfg, ocfg = pair(sk, oracle, "matern", (1, 1, 1.5), quadspec=(256, 16))
+    ks, _ = sk.kernel_values(cfg, rs, k0=3.0, param_derivative=True)
+    assert abs(ks[0] - np.pi / 2) <= 1e-9
+
+
+def test_callback_sdf_equals_catalogue(sk, oracle):
+    rs = 10.0 ** np.linspace(-5, 0, 150)
+    cat = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5), quadspec=(256, 16))
+    cb = sk.AdaptiveKernelConfig(lambda w: (1.0 + w * w) ** -2.0, quadspec=(256, 16))
+    a, ea = sk.kernel_values(cat, rs, k0=np.pi / 2)
+    b, eb = sk.kernel_values(cb, rs)  # k0 through the batched closure
+    assert np.abs(a - b).max() <= 1e-11 and np.abs(ea - eb).max() <= 1e-11
+    assert cb.last_stats()["n_panels"] == cat.last_stats()["n_panels"]
+    # scalar-only Python closures work too
+    import math
+    cb2 = sk.AdaptiveKernelConfig(lambda w: math.exp(-abs(float(w))), quadspec=(64, 4))
+    c, _ = sk.kernel_values(cb2, np.array([0.0, 0.1, 1.0]))
+    assert np.abs(c - oracle.exponential_cov(np.array([0.0, 0.1, 1.0]))).max() <= 1e-7
+
+
+def test_quadspec_warning_and_errors(sk):
+    with pytest.warns(UserWarning):
+        cfg = sk.AdaptiveKernelConfig(sk.SDF.exponential(1.0), tol=1e-13)
+    assert cfg.quadspec == (4096, 1)
+    with pytest.raises(sk.SpectralKernelsError) as e:
+        sk.AdaptiveKernelConfig(sk.SDF.exponential(1.0), alpha=1.5)
+    assert e.value.code == 1
+    with pytest.raises(sk.SpectralKernelsError):
+        sk.AdaptiveKernelConfig(sk.SDF.exponential(1.0), logw=True)
+    # NaN SDF: int1 and int2 are both NaN -> never accepted -> bisected down to b-a < 1e-16
+    # (src/quadrature.jl:165 precedence quirk, src/utils.jl:28-36)
+    bad = sk.AdaptiveKernelConfig(lambda w: w * float("nan"), quadspec=(8, 2))
+    with pytest.raises(sk.SpectralKernelsError) as e:
+        sk.kernel_values(bad, np.array([0.5, 1.0]), k0=1.0)
+    assert e.value.code == 2 and "split too many times" in str(e.value)
+
+
+@pytest.mark.parametrize("w", [8, 10, 12, 14, 16])
+def test_panel_sums_seam(sk, oracle, w):
+    # finufft1d3 seam (src/utils.jl:10): NUFFT kernels vs direct-sum kernel vs oracle
+    rng = np.random.default_rng(w)
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5), quadspec=(256, 16), nufft_width=w)
+    M = 4096
+    lo = 1000.0
+    hi = lo + M / 2.0  # panel width for r_hi = 1
+    nodes = np.sort(rng.uniform(lo, hi, 2500))
+    nodes[0], nodes[-1] = lo, hi
+    coef = rng.uniform(0.0, 1.0, nodes.size) / nodes.size
+    xs = np.concatenate([[0.0, 1.0], 10.0 ** rng.uniform(-7, 0, 400)])
+    ref = oracle.direct_sums(nodes, coef, xs)
+    d = sk.panel_sums(cfg, nodes, coef, lo, hi, xs, method="direct")
+    f = sk.panel_sums(cfg, nodes, coef, lo, hi, xs, method="nufft")
+    assert np.abs(d - ref).max() <= 1e-13
+    assert np.abs(f - ref).max() <= 30 * 10.0 ** (1 - w) + 3e-13
+    with pytest.raises(sk.SpectralKernelsError):
+        sk.panel_sums(cfg, nodes, coef, lo, hi, 4 * xs + 1.0)  # space-bandwidth product too large
+
+
+def test_nonpow2_quadspec(sk, oracle):
+    rs = 10.0 ** np.linspace(-4, 0, 80)
+    for quadspec in [(100, 3), (96, 10), (33, 1)]:
+        cfg, ocfg = pair(sk, oracle, "matern", (1, 1, 1.5), quadspec=quadspec)
+        check_pair(sk, oracle, cfg, ocfg, rs, np.pi / 2, 1e-8)
