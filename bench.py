@@ -132,7 +132,8 @@ def main():
     dom = max(acc, key=lambda k: acc[k]["total_ms"])
     # algorithmic bytes per launch: interp/accum per active lag, gen/spread per panel
     M = cfg.quadspec[0] * cfg.quadspec[1]
-    alg_bytes = {"interp": 24.0, "accum": 40.0}
+    # interp: read r (8) + write I2 and |I2-I1| (16) + read-modify-write of the K and err accumulators (32)
+    alg_bytes = {"interp": 56.0}
     rl = {}
     for k, v in acc.items():
         if v["launches"] == 0:
@@ -141,10 +142,8 @@ def main():
         items = v["active_items"] / v["launches"]
         if k in alg_bytes:
             b = alg_bytes[k] * items
-        elif k == "gen":
-            b = 48.0 * M  # nodes + real weights of both rules (M + 2M) x (8 + 8)
         elif k == "spread":
-            b = 48.0 * M + 2 * 16.0 * (items / 2)  # read sources, write two complex grids
+            b = 48.0 * M + 16.0 * items  # nodes + weights of both rules (M + 2M) x (8 + 8); write two complex grids
         elif k == "fft":
             b = 2 * 16.0 * items  # read + write both grids once
         else:

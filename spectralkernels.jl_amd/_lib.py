@@ -26,11 +26,11 @@ class Stats(C.Structure):
                 ("last_b", C.c_double)]
 
 
-K_NAMES = ["gen", "spread", "fft", "interp", "accum", "advance"]
+K_NAMES = ["spread", "fft", "interp", "advance"]
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("total_ms", C.c_double * 6), ("launches", C.c_int64 * 6), ("active_items", C.c_int64 * 6)]
+    _fields_ = [("total_ms", C.c_double * 4), ("launches", C.c_int64 * 4), ("active_items", C.c_int64 * 4)]
 
 
 _lib = None

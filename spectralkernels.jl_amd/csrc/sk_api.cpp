@@ -4,6 +4,7 @@
 #include <rocfft/rocfft.h>
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -61,6 +62,7 @@ struct sk_config {
   EsTables tab;
   // device
   DevConst dc;
+  EsConst ec;
   DevBuffers db;
   std::vector<void*> owned;  // device allocations freed at destroy
   rocfft_plan plan = nullptr;
@@ -72,6 +74,8 @@ struct sk_config {
   size_t ws_bytes = 0;
   DevState* h_state = nullptr;  // pinned
   int* d_flags = nullptr;
+  void* blk_buf = nullptr;
+  size_t blk_cap = 0;
   int* h_flags = nullptr;
   long long* h_nuniq = nullptr;
   hipStream_t own_stream = nullptr;
@@ -171,6 +175,32 @@ static void build_positions(const sk_config* cfg, int variant, int rule, std::ve
   for (int64_t i = 0; i < n1; ++i) cellstart[(size_t)i + 1] = cellstart[(size_t)i] + cnt[(size_t)i + 1];
 }
 
+// Spread work list of one variant: tiles of <= 64 cells holding <= ~256 touching sources where the
+// node density allows it (Gauss nodes cluster like 1/m^2 at every sub-panel edge), heaviest first.
+static void build_tiles(const sk_config* cfg, const std::vector<int> cs[2], std::vector<int2>& tiles) {
+  const int64_t n1 = cfg->dc.n1;
+  const int W = cfg->dc.w;
+  struct T { int key, start, len, cnt; };
+  std::vector<T> all;
+  for (int rule = 0; rule < 2; ++rule) {
+    const std::vector<int>& c = cs[rule];
+    auto touching = [&](int64_t a, int64_t b) {  // sources in cells [a - W/2, b + W/2)
+      int64_t lo = a - W / 2 < 0 ? 0 : a - W / 2, hi = b + W / 2 > n1 ? n1 : b + W / 2;
+      return c[(size_t)hi] - c[(size_t)lo];
+    };
+    int64_t start = 0;
+    while (start < n1) {
+      int64_t end = start + 8 > n1 ? n1 : start + 8;
+      while (end < n1 && end - start < 64 && touching(start, end + 1) <= 256) ++end;
+      all.push_back({(rule << 30) | (int)start, (int)start, (int)(end - start), touching(start, end)});
+      start = end;
+    }
+  }
+  std::stable_sort(all.begin(), all.end(), [](const T& a, const T& b) { return a.cnt > b.cnt; });
+  tiles.clear();
+  for (const T& t : all) tiles.push_back(make_int2(t.key, t.len));
+}
+
 static int ensure_ws(sk_config* cfg, size_t bytes) {
   if (bytes <= cfg->ws_bytes) return SK_OK;
   if (cfg->ws) HIPCHK(hipFree(cfg->ws));
@@ -253,14 +283,26 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   db.xs = d_uxs;
   db.ks = d_ks;
   db.errs = d_errs;
-  db.P = d_scratch4n;
-  db.E = db.P + n;
-  db.tmpI = db.E + n;
-  db.tmpE = db.tmpI + n;
+  db.accK[0] = d_scratch4n;
+  db.accK[1] = db.accK[0] + n;
+  db.accE[0] = db.accK[1] + n;
+  db.accE[1] = db.accE[0] + n;
+  db.P[0] = db.accE[1] + n;
+  db.P[1] = db.P[0] + n;
   db.fvals = cfg->d_fvals;
-  HIPCHK(hipMemsetAsync(d_ks, 0, sizeof(double) * n, st));
-  HIPCHK(hipMemsetAsync(d_errs, 0, sizeof(double) * n, st));
-  HIPCHK(hipMemsetAsync(db.P, 0, sizeof(double) * 2 * n, st));
+  {
+    const size_t nblk = (size_t)((n + 255) / 256) + 1;
+    if (nblk > cfg->blk_cap) {
+      if (cfg->blk_buf) HIPCHK(hipFree(cfg->blk_buf));
+      cfg->blk_buf = nullptr;
+      cfg->blk_cap = 0;
+      HIPCHK(hipMalloc(&cfg->blk_buf, nblk * 2 * (sizeof(double) + sizeof(unsigned int) + sizeof(int))));
+      cfg->blk_cap = nblk * 2;
+    }
+    db.blk_max = (double*)cfg->blk_buf;
+    db.blk_hi = (unsigned int*)(db.blk_max + cfg->blk_cap);
+    db.blk_nan = (int*)(db.blk_hi + cfg->blk_cap);
+  }
   launch_init(cfg->dc, db, n, k0, ks0, st);
   const bool cb = (cfg->dc.sdf_kind == SK_SDF_CALLBACK);
   int slot = 0;
@@ -282,15 +324,14 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       HIPCHK(hipMemcpyAsync(&db.state[slot].fb, &fb, sizeof(double), hipMemcpyHostToDevice, st));
     }
     for (int r = 0; r < R; ++r) {
-      { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, slot, st); }
-      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, db, slot, st); }
+      if (cb) launch_tail(cfg->dc, db, slot, st);
+      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->ec, db, slot, st); }
       {
         EvScope e(cfg, st, SK_K_FFT);
         int rc = run_fft(cfg, st);
         if (rc) return rc;
       }
-      { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, db, slot, n, st); }
-      { EvScope e(cfg, st, SK_K_ACCUM); launch_accum(cfg->dc, db, slot, n, st); }
+      { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->ec, db, slot, n, st); }
       { EvScope e(cfg, st, SK_K_ADVANCE); launch_advance(cfg->dc, db, slot, st); }
       slot ^= 1;
       stt.n_steps_launched++;
@@ -303,7 +344,6 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       R = R < 16 ? 2 * R : 16;
     }
   }
-  launch_final(cfg->dc, db, slot, n, st);
   HIPCHK(hipGetLastError());
   // stats + trace
   stt.n_outer = hs->n_outer;
@@ -327,11 +367,9 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         cfg->ktimes.launches[r.kid] += 1;
       }
     }
-    cfg->ktimes.active_items[SK_K_GEN] = 3 * cfg->M * hs->n_panels;
     cfg->ktimes.active_items[SK_K_SPREAD] = 2 * cfg->dc.n2 * hs->n_panels;
     cfg->ktimes.active_items[SK_K_FFT] = 2 * cfg->dc.n2 * hs->n_panels;
     cfg->ktimes.active_items[SK_K_INTERP] = hs->sum_active;
-    cfg->ktimes.active_items[SK_K_ACCUM] = hs->sum_active;
     cfg->ktimes.active_items[SK_K_ADVANCE] = hs->n_panels;
     cfg->ev_recs.clear();
     cfg->ev_used = 0;
@@ -345,6 +383,7 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   std::memset(&cfg->stats, 0, sizeof(cfg->stats));
   cfg->trace.clear();
   if (n == 0) return SK_OK;
+  if (n > (size_t)0x7fffffff) return fail(SK_EINVAL, "at most 2^31-1 lags per call");
   HIPCHK(hipSetDevice(cfg->device));
   HIPCHK(hipMemsetAsync(cfg->d_flags, 0, 2 * sizeof(int), st));
   launch_check_sorted(d_xs, (long long)n, cfg->d_flags, st);
@@ -355,21 +394,21 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   const size_t a8 = ((n * 8 + 255) / 256) * 256;
   if (!cfg->h_flags[0]) {
     // strictly increasing: outputs double as accumulators
-    int rc = ensure_ws(cfg, 4 * a8);
+    int rc = ensure_ws(cfg, 6 * a8);
     if (rc) return rc;
     cfg->stats.n_unique = (int64_t)n;
     return run_core(cfg, d_xs, (long long)n, k0, ks0, d_vals, d_errs, (double*)cfg->ws, st);
   }
   // src/adaptive.jl:99-120: unique + sort, then gather back
   const size_t tb = sort_unique_temp_bytes((long long)n);
-  int rc = ensure_ws(cfg, 8 * a8 + tb + 256);
+  int rc = ensure_ws(cfg, 10 * a8 + tb + 256);
   if (rc) return rc;
   char* base = (char*)cfg->ws;
   double* uxs = (double*)base; base += a8;
   long long* inv = (long long*)base; base += a8;
   double* ks = (double*)base; base += a8;
   double* errs = (double*)base; base += a8;
-  double* scr = (double*)base; base += 4 * a8;
+  double* scr = (double*)base; base += 6 * a8;
   long long* d_nu = (long long*)base; base += 256;
   sort_unique(d_xs, (long long)n, uxs, inv, d_nu, base, tb, st);
   HIPCHK(hipMemcpyAsync(cfg->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -488,20 +527,32 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   } while (0)
   UP(cfg->leg[0], dc.leg_no1); UP(cfg->leg[1], dc.leg_wt1); UP(cfg->leg[2], dc.leg_no2); UP(cfg->leg[3], dc.leg_wt2);
   UP(cfg->jac[0], dc.jac_no1); UP(cfg->jac[1], dc.jac_wt1); UP(cfg->jac[2], dc.jac_no2); UP(cfg->jac[3], dc.jac_wt2);
-  UP(cfg->tab.poly, dc.poly); UP(cfg->tab.cheb, dc.cheb); UP(cfg->tab.deconv, dc.deconv);
-  for (int variant = 0; variant < 2; ++variant)
-    for (int rule = 0; rule < 2; ++rule) {
-      if (variant == 1 && cfg->p == 0.0) {
+  UP(cfg->tab.deconv, dc.deconv);
+  std::memset(&cfg->ec, 0, sizeof(cfg->ec));
+  std::memcpy(cfg->ec.poly, cfg->tab.poly.data(), cfg->tab.poly.size() * sizeof(double));
+  std::memcpy(cfg->ec.cheb, cfg->tab.cheb.data(), cfg->tab.cheb.size() * sizeof(double));
+  for (int variant = 0; variant < 2; ++variant) {
+    if (variant == 1 && cfg->p == 0.0) {
+      for (int rule = 0; rule < 2; ++rule) {
         dc.pos[1][rule] = dc.pos[0][rule];
         dc.cellstart[1][rule] = dc.cellstart[0][rule];
-        continue;
       }
-      std::vector<double> pos;
-      std::vector<int> cs;
-      build_positions(cfg, variant, rule, pos, cs);
-      UP(pos, dc.pos[variant][rule]);
-      UP(cs, dc.cellstart[variant][rule]);
+      dc.tiles[1] = dc.tiles[0];
+      dc.ntiles[1] = dc.ntiles[0];
+      continue;
     }
+    std::vector<int> cs2[2];
+    for (int rule = 0; rule < 2; ++rule) {
+      std::vector<double> pos;
+      build_positions(cfg, variant, rule, pos, cs2[rule]);
+      UP(pos, dc.pos[variant][rule]);
+      UP(cs2[rule], dc.cellstart[variant][rule]);
+    }
+    std::vector<int2> tiles;
+    build_tiles(cfg, cs2, tiles);
+    UP(tiles, dc.tiles[variant]);
+    dc.ntiles[variant] = (int)tiles.size();
+  }
 #undef UP
   DevBuffers& db = cfg->db;
   std::memset(&db, 0, sizeof(db));
@@ -511,7 +562,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     if (rc) { sk_config_destroy(cfg); return rc; }         \
   } while (0)
   DA(2, db.state); DA(kStackCap, db.stack); DA(kTraceCap, db.trace);
-  DA((size_t)cfg->M, db.src1); DA((size_t)2 * cfg->M, db.src2); DA((size_t)2 * dc.n2, db.fft);
+  DA((size_t)2 * dc.n2, db.fft);
   DA((size_t)3 * cfg->M, cfg->d_fvals);
   DA(2, cfg->d_flags);
 #undef DA
@@ -562,6 +613,7 @@ void sk_config_destroy(sk_config* cfg) {
   if (cfg->fft_work) hipFree(cfg->fft_work);
   for (void* p : cfg->owned) hipFree(p);
   if (cfg->ws) hipFree(cfg->ws);
+  if (cfg->blk_buf) hipFree(cfg->blk_buf);
   if (cfg->h_state) hipHostFree(cfg->h_state);
   if (cfg->h_flags) hipHostFree(cfg->h_flags);
   if (cfg->h_nuniq) hipHostFree(cfg->h_nuniq);
@@ -681,7 +733,7 @@ int sk_panel_sums(sk_config* cfg, const double* nodes, const double* coef, size_
     launch_seam_deconv(dc, cfg->db.fft, st);
     rc = run_fft(cfg, st);
     if (rc) return done(rc);
-    launch_seam_interp(dc, cfg->db.fft, d_xs, (int64_t)n, Cx, r_hi, tau, theta_scale, d_re, d_im, st);
+    launch_seam_interp(dc, cfg->ec, cfg->db.fft, d_xs, (int64_t)n, Cx, r_hi, tau, theta_scale, d_re, d_im, st);
   }
   if (hipMemcpyAsync(out_re, d_re, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipMemcpyAsync(out_im, d_im, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||

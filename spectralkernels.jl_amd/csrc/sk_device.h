@@ -28,9 +28,18 @@ struct DevConst {
   const double* jac_no1; const double* jac_wt1; const double* jac_no2; const double* jac_wt2;
   const double* pos[2][2];      // [variant][rule] source positions in grid units, P_j in [w/2, n1-w/2]
   const int* cellstart[2][2];   // [variant][rule] first source with floor(P_j) >= cell, n1+1 entries
-  const double* poly;           // (w/2) x 2 x nco piecewise-polynomial coefficients
-  const double* cheb;           // ncheb Chebyshev coefficients of 1/phi_hat
   const double* deconv;         // n1/2+1 values of 1/phi_hat(2 pi l/n2)
+  // spread work list per variant: (rule << 30 | first cell, cells <= 64) sorted by decreasing
+  // source count, so that the dense sub-panel-edge tiles start first
+  const int2* tiles[2];
+  int ntiles[2];
+};
+
+// ES-kernel tables passed BY VALUE (kernarg segment => scalar loads, no LDS, no vector loads):
+// piecewise-polynomial coefficients and the Chebyshev series of 1/phi_hat.
+struct EsConst {
+  double poly[(kMaxWidth / 2) * 2 * kMaxNco];
+  double cheb[20];
 };
 
 struct PanelParams {
@@ -43,6 +52,14 @@ struct PanelParams {
   int jacobi;           // Gauss-Jacobi rule on the first sub-panel (p != 0 and pa == 0)
 };
 
+// Target-independent pieces of the convergence test of one outer panel
+// (src/adaptive.jl:204-233): truncation bound = min(t1, t2num / x^((dim+1)/2)).
+struct TailScalars {
+  double t1, t2num;
+  int crit;             // effective criteria for this panel (:panel after a NaN tail fit)
+  int pad;
+};
+
 struct DevState {
   PanelParams pp;
   double a, b;          // outer panel (src/adaptive.jl:152)
@@ -50,7 +67,13 @@ struct DevState {
   double k0abs;         // |k0|
   double ks0;           // value stored at x == 0
   long long n, ix1, hi, hi_prev;  // active lags are [ix1, hi)
-  int crit, done, stack_len, retire_pending;
+  TailScalars tail;     // of the current outer panel
+  // confirmed running sums live in acc buffer `conf` (valid iff has_acc); every evaluation writes
+  // the optimistic sums into the other buffer, an accepted panel flips `conf`.  P (the current
+  // outer panel's accepted sub-panel sums, src/adaptive.jl:183-198 uses them) is only
+  // materialised while an outer panel is being bisected: buffer `pc`, valid iff p_valid.
+  int conf, has_acc, pc, p_valid;
+  int crit, done, stack_len, pad0;
   unsigned long long max_err_bits;  // atomicMax over the bit pattern of |I2-I1| >= 0
   unsigned long long hi_new;        // atomicMax over i+1 of unconverged lags
   int nan1, nan2;
@@ -64,29 +87,29 @@ struct DevBuffers {
   DevState* state;          // 2 slots (ping-pong)
   double2* stack;           // kStackCap (a,b) pairs
   TraceRec* trace;          // kTraceCap
-  double2* src1; double2* src2;   // pre-phased coefficients, M and 2M
   double2* fft;             // 2 x n2 complex (rule 1, rule 2)
   const double* fvals;      // callback mode: S(omega_j) for rule 1 (M) then rule 2 (2M)
   const double* xs;         // sorted unique lags
-  double* ks; double* errs; // accumulators (output, sorted-unique order)
-  double* P; double* E;     // outer-panel partial sums
-  double* tmpI; double* tmpE;
+  double* ks; double* errs; // outputs (sorted-unique order): always the latest optimistic totals
+  double* accK[2]; double* accE[2];  // ping-pong running sums of the active lags
+  double* P[2];             // ping-pong outer-panel partial sums (bisection only)
+  // per-workgroup partial reductions of k_interp (no same-address atomics): max |I2-I1| bits,
+  // highest unconverged lag + 1, NaN flags (bit 0: I1, bit 1: I2)
+  double* blk_max; unsigned int* blk_hi; int* blk_nan;
 };
 
 // launchers (sk_kernels.hip)
 void launch_init(const DevConst& dc, const DevBuffers& db, long long n, double k0, double ks0, hipStream_t st);
-void launch_gen(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);
-void launch_spread(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);
-void launch_interp(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st);
-void launch_accum(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st);
+void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);  // callback SDFs only
+void launch_spread(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, hipStream_t st);
+void launch_interp(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, long long n, hipStream_t st);
 void launch_advance(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);
-void launch_final(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st);
 
 // seam kernels for sk_panel_sums
 void launch_seam_spread(const DevConst& dc, const double* nodes, const double* coef, int64_t M, double Cx, double X,
                         double kappa, double2* fft, hipStream_t st);
 void launch_seam_deconv(const DevConst& dc, double2* fft, hipStream_t st);
-void launch_seam_interp(const DevConst& dc, const double2* fft, const double* xs, int64_t n, double Cx, double r_hi,
+void launch_seam_interp(const DevConst& dc, const EsConst& ec, const double2* fft, const double* xs, int64_t n, double Cx, double r_hi,
                         double tau, double theta_scale, double* out_re, double* out_im, hipStream_t st);
 void launch_direct(const double* nodes, const double* coef, int64_t M, const double* xs, int64_t n, double* out_re,
                    double* out_im, hipStream_t st);

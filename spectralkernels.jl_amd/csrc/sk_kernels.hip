@@ -1,15 +1,15 @@
 // sk_kernels.hip -- gfx950 kernels of the kernel_values hot path.
 //
 // One (sub)panel evaluation ("step") is
-//   k_gen     nodes, SDF, Gauss weights, pre-phase      (src/quadrature.jl:49-95 updatequadbufs!)
-//   k_spread  output-driven ES spreading + deconvolution (type-3 NUFFT, replaces finufft1d3,
+//   k_spread  nodes, SDF, Gauss weights, pre-phase (src/quadrature.jl:49-95 updatequadbufs!) staged in
+//             LDS, then tile-wise ES spreading + deconvolution (type-3 NUFFT, replaces finufft1d3,
 //   rocFFT    length n2, batch 2 (m- and 2m-rule)         src/utils.jl:10 / src/quadrature.jl:109-110)
-//   k_interp  interpolation at the active lags, post-phase, scaling, |I2-I1|, max reduction
-//                                                        (src/quadrature.jl:130-136, :250-258)
-//   k_accum   accept/reject (src/quadrature.jl:260-263), outer accumulation (src/adaptive.jl:163-164),
-//             convergence predicate (src/adaptive.jl:183-198, :222-233)
-//   k_advance scalar transition: bisection stack (src/quadrature.jl:268-270), next outer panel
-//             (src/adaptive.jl:149-152), tail fit (src/adaptive.jl:204-220)
+//   k_interp  applies the previous step's pending sums (src/quadrature.jl:261-262, src/adaptive.jl:
+//             163-164, :194), interpolates at the active lags, post-phase, scaling, |I2-I1| and its
+//             max (src/quadrature.jl:130-136, :250-258) and the speculative convergence predicate
+//             (src/adaptive.jl:183-198, :222-233)
+//   k_advance scalar transition: accept/reject (src/quadrature.jl:260), bisection stack (:268-270),
+//             next outer panel (src/adaptive.jl:149-152), tail fit (src/adaptive.jl:204-220)
 // All state lives in HBM (DevState ping-pong), so steps run back to back with no host hop.
 #include <cstring>
 #include <cmath>
@@ -62,6 +62,36 @@ __device__ void set_panel(DevState& s, const DevConst& dc, const double* xs, dou
   pp.jacobi = (dc.p != 0.0 && pa == 0.0) ? 1 : 0;
 }
 
+// src/adaptive.jl:204-220 with all 1000 sample points equal to b (minimum-norm least squares),
+// followed by the target-independent factors of truncation_error_estimate (:222-229).
+__device__ void tail_scalars(DevState& s, const DevConst& dc) {
+  TailScalars t;
+  t.crit = s.crit;
+  t.t1 = 0.0;
+  t.t2num = 0.0;
+  t.pad = 0;
+  if (s.crit != SK_CRIT_PANEL) {
+    const double b = s.b;
+    const double fb = fabs(s.fb);
+    double d;
+    if (!dc.has_tail) {
+      double L = log(b), y = log(fb);
+      d = isfinite(y) ? L * y / (1.0 + L * L) : __builtin_nan("");
+    } else {
+      d = dc.tail;
+    }
+    d -= dc.alpha;
+    const double c = (pow(b, d) * fb) / pow(b, 2.0 * d);
+    if (isnan(c) || isnan(d)) {
+      t.crit = SK_CRIT_PANEL;  // src/adaptive.jl:170-175 (persists: k_advance copies it into s.crit)
+    } else {
+      t.t1 = -c / (d + dc.dim) * pow(b, d + dc.dim);
+      t.t2num = c * pow(b, d + (dc.dim - 1) * 0.5) / (2.0 * SK_PI);
+    }
+  }
+  s.tail = t;
+}
+
 // src/adaptive.jl:149-152: next outer panel or finish.
 __device__ void setup_outer(DevState& s, const DevConst& dc, const double* xs) {
   if (s.hi > s.ix1) {
@@ -70,33 +100,20 @@ __device__ void setup_outer(DevState& s, const DevConst& dc, const double* xs) {
     s.a = a;
     s.b = b;
     s.n_outer += 1;
-    if (dc.sdf_kind != SK_SDF_CALLBACK) s.fb = sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, b);
     set_panel(s, dc, xs, a, b);
+    if (dc.sdf_kind != SK_SDF_CALLBACK) {
+      s.fb = sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, b);
+      tail_scalars(s, dc);
+    }
   } else {
     s.done = 1;
   }
 }
 
-// src/adaptive.jl:204-220 with all 1000 sample points equal to b: minimum-norm least squares.
-__device__ __forceinline__ void tail_fit(const DevConst& dc, double b, double fb_in, double& tc, double& td) {
-  double fb = fabs(fb_in);
-  double d;
-  if (!dc.has_tail) {
-    double L = log(b), y = log(fb);
-    d = isfinite(y) ? L * y / (1.0 + L * L) : __builtin_nan("");
-  } else {
-    d = dc.tail;
-  }
-  d -= dc.alpha;
-  tc = (pow(b, d) * fb) / pow(b, 2.0 * d);
-  td = d;
-}
-
-// src/adaptive.jl:222-229
-__device__ __forceinline__ double trunc_est(double b, double x, double c, double d, int dim) {
-  double t1 = -c / (d + dim) * pow(b, d + dim);
-  double t2 = c * pow(b, d + (dim - 1) * 0.5) / (2.0 * SK_PI * pow(x, (dim + 1) * 0.5));
-  return fmin(t1, t2);
+// truncation_error_estimate (src/adaptive.jl:222-229) for lag x
+__device__ __forceinline__ double trunc_est(const TailScalars& t, double x, int dim) {
+  double xp = (dim == 1) ? x : ((dim == 2) ? x * sqrt(x) : pow(x, (dim + 1) * 0.5));
+  return fmin(t.t1, t.t2num / xp);
 }
 
 __device__ __forceinline__ bool step_accept(const DevState& s, double tol) {
@@ -116,13 +133,59 @@ __global__ void k_init(DevConst dc, DevBuffers db, long long n, double k0, doubl
   s.a = 0.0;
   s.b = 0.0;
   s.hi_new = (unsigned long long)s.ix1;
+  if (s.ix1 == 1) {  // src/adaptive.jl:132-146
+    db.ks[0] = ks0;
+    db.errs[0] = __builtin_nan("");
+  }
   setup_outer(s, dc, db.xs);
   db.state[0] = s;
   db.state[1] = s;
 }
 
-__global__ void k_advance(DevConst dc, DevBuffers db, int slot) {
+// Callback SDFs: the host uploads S(b) into state.fb before the step, then this computes the tail.
+__global__ void k_tail(DevConst dc, DevBuffers db, int slot) {
+  DevState& s = db.state[slot];
+  if (s.done) return;
+  tail_scalars(s, dc);
+}
+
+__global__ void __launch_bounds__(256) k_advance(DevConst dc, DevBuffers db, int slot) {
+  __shared__ double smax[256];
+  __shared__ unsigned int shi[256];
+  __shared__ int snan[256];
+  {
+    // reduce the per-workgroup partials that k_interp wrote for the active range [0, hi)
+    const DevState& s0 = db.state[slot];
+    const long long nb = s0.done ? 0 : (s0.hi + 255) / 256;
+    double m = 0.0;
+    unsigned int h = 0u;
+    int f = 0;
+    for (long long b = threadIdx.x; b < nb; b += blockDim.x) {
+      m = fmax(m, db.blk_max[b]);
+      const unsigned int hb = db.blk_hi[b];
+      h = hb > h ? hb : h;
+      f |= db.blk_nan[b];
+    }
+    smax[threadIdx.x] = m;
+    shi[threadIdx.x] = h;
+    snan[threadIdx.x] = f;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) {
+        smax[threadIdx.x] = fmax(smax[threadIdx.x + off], smax[threadIdx.x]);
+        shi[threadIdx.x] = shi[threadIdx.x + off] > shi[threadIdx.x] ? shi[threadIdx.x + off] : shi[threadIdx.x];
+        snan[threadIdx.x] |= snan[threadIdx.x + off];
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x != 0) return;
   DevState s = db.state[slot];
+  s.nan1 = snan[0] & 1;
+  s.nan2 = (snan[0] >> 1) & 1;
+  // a NaN in int1 makes maximum(_err) NaN in the reference, which is never < tol*k0
+  s.max_err_bits = (unsigned long long)__double_as_longlong(s.nan1 ? __builtin_nan("") : smax[0]);
+  s.hi_new = shi[0] > (unsigned long long)s.ix1 ? (unsigned long long)shi[0] : (unsigned long long)s.ix1;
   if (!s.done) {
     const bool accept = step_accept(s, dc.tol);
     const long long nact = s.hi - s.ix1;
@@ -137,24 +200,23 @@ __global__ void k_advance(DevConst dc, DevBuffers db, int slot) {
     }
     s.n_panels += 1;
     s.sum_active += nact;
-    s.retire_pending = 0;
+    s.hi_prev = s.hi;
     if (!s.nan1 && s.nan2) {  // src/quadrature.jl:165 (throws only when int1 is NaN-free)
       s.done = -SK_ENAN;
     } else if (accept) {
       s.n_accepted += 1;
+      s.conf ^= 1;  // the optimistic sums of this evaluation become the confirmed ones
+      s.has_acc = 1;
       if (s.stack_len > 0) {
+        s.pc ^= 1;  // k_interp stored P + I2 in the other P buffer
+        s.p_valid = 1;
         double2 ab = db.stack[--s.stack_len];
         set_panel(s, dc, db.xs, ab.x, ab.y);
       } else {
         // outer panel complete: src/adaptive.jl:168-199
-        if (s.crit != SK_CRIT_PANEL) {
-          double tc, td;
-          tail_fit(dc, s.b, s.fb, tc, td);
-          if (isnan(tc) || isnan(td)) s.crit = SK_CRIT_PANEL;
-        }
-        s.hi_prev = s.hi;
+        s.p_valid = 0;
+        s.crit = s.tail.crit;  // a NaN tail fit switches to :panel for the rest of the call
         s.hi = (long long)s.hi_new;
-        s.retire_pending = 1;
         setup_outer(s, dc, db.xs);
       }
     } else {
@@ -171,55 +233,16 @@ __global__ void k_advance(DevConst dc, DevBuffers db, int slot) {
     s.hi_new = (unsigned long long)s.ix1;
     s.nan1 = 0;
     s.nan2 = 0;
-  } else {
-    s.retire_pending = 0;
   }
   db.state[slot ^ 1] = s;
 }
 
-// ------------------------------------------------------------------ k_gen
-
-__global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int slot) {
-  const DevState& s = db.state[slot];
-  if (s.done) return;
-  const PanelParams pp = s.pp;
-  const int64_t M = dc.M;
-  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= 3 * M) return;
-  const int rule = j < M ? 0 : 1;
-  const int64_t jj = rule ? j - M : j;
-  const int64_t mr = rule ? 2 * dc.m : dc.m;
-  const int64_t sp = jj / mr, q = jj - sp * mr;
-  const double pa = pp.pa, pb = pp.pb;
-  double sa = (sp == 0) ? pa : pa + (pb - pa) * ((double)sp / (double)dc.k);
-  double sb = (sp + 1 == dc.k) ? pb : pa + (pb - pa) * ((double)(sp + 1) / (double)dc.k);
-  const double bmad2 = 0.5 * (sb - sa), bpad2 = 0.5 * (sb + sa);
-  double w, wq;
-  if (pp.jacobi && sp == 0) {  // src/quadrature.jl:61-78
-    const double* no = rule ? dc.jac_no2 : dc.jac_no1;
-    const double* wt = rule ? dc.jac_wt2 : dc.jac_wt1;
-    w = bmad2 * no[q] + bpad2;
-    wq = wt[q] * pow(bmad2, dc.p + 1.0);
-  } else {  // src/quadrature.jl:82-92
-    const double* no = rule ? dc.leg_no2 : dc.leg_no1;
-    const double* wt = rule ? dc.leg_wt2 : dc.leg_wt1;
-    w = bmad2 * no[q] + bpad2;
-    wq = wt[q] * bmad2 * (dc.p == 0.0 ? 1.0 : pow(w, dc.p));
-  }
-  const double f = (dc.sdf_kind == SK_SDF_CALLBACK) ? db.fvals[j] : sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, w);
-  const double cj = wq * f;
-  const double P = dc.pos[pp.jacobi][rule][jj];
-  const double u = (P - 0.5 * (double)dc.n1) * dc.delta;
-  const double2 ph = cis_turns_prod(pp.kappa, u);
-  double2* dst = rule ? db.src2 : db.src1;
-  dst[jj] = make_double2(cj * ph.x, cj * ph.y);
-}
-
 // ------------------------------------------------------------------ ES kernel evaluation
 
-// Even/odd Horner evaluation of pair q at offset y: E(y^2), O(y^2).
+// Even/odd Horner evaluation of pair q at offset y: E(y^2), O(y^2).  `poly` is a kernel-argument
+// pointer and q is a compile-time constant after unrolling, so the coefficient loads are scalar.
 template <int W>
-__device__ __forceinline__ void es_pair(const double* __restrict__ poly, int q, double y2, double& E, double& O) {
+__device__ __forceinline__ void es_pair(const double* poly, int q, double y2, double& E, double& O) {
   constexpr int NCO = W / 2 + 2;
   const double* pe = poly + q * 2 * NCO;
   const double* po = pe + NCO;
@@ -232,61 +255,166 @@ __device__ __forceinline__ void es_pair(const double* __restrict__ poly, int q, 
   }
 }
 
-// ------------------------------------------------------------------ k_spread
-
+// Stages the ES tables (kernarg) in LDS; every later read is a same-address LDS broadcast, which
+// runs on the LDS pipe beside the FP64 VALU work and costs neither SGPRs nor vector-memory slots.
 template <int W>
-__global__ void __launch_bounds__(256) k_spread(DevConst dc, DevBuffers db, int slot) {
-  constexpr int NCO = W / 2 + 2;
-  __shared__ double spoly[(W / 2) * 2 * NCO];
+__device__ __forceinline__ void stage_es_tables(const EsConst& ec, double* s_poly, double* s_cheb) {
+  constexpr int NP = (W / 2) * 2 * (W / 2 + 2);
+  const double* gp = ec.poly;
+  const double* gc = ec.cheb;
+  for (int t = threadIdx.x; t < NP; t += blockDim.x) s_poly[t] = gp[t];
+  if (s_cheb)
+    for (int t = threadIdx.x; t < 20; t += blockDim.x) s_cheb[t] = gc[t];
+}
+
+// ------------------------------------------------------------------ k_spread (nodes + spreading)
+
+constexpr int kTileCells = 64;   // spread-grid cells per workgroup
+constexpr int kSpreadThreads = 256;
+
+// One workgroup owns kTileCells consecutive cells of one rule's spread grid.  Per batch of 256
+// sources whose support touches the tile: (0) node, SDF value, Gauss weight and pre-phase of the
+// source (updatequadbufs!, src/quadrature.jl:49-95) are computed in registers and staged in LDS,
+// (1) its W kernel weights are staged in LDS, (2) every cell gathers from the staged batch in a
+// fixed order (deterministic, no atomics).  The tile is deconvolved and written in FFT order.
+template <int W>
+__global__ void __launch_bounds__(kSpreadThreads) k_spread(DevConst dc, EsConst ec, DevBuffers db, int slot) {
+  __shared__ double s_w[kSpreadThreads * (W + 1)];
+  __shared__ double2 s_c[kSpreadThreads];
+  __shared__ int s_l0[kSpreadThreads];
+  __shared__ double2 s_red[kSpreadThreads];
+  // s_first[c + W]: first staged source whose first cell l0 is >= c (c relative to the tile, -W..TC+W)
+  __shared__ int s_first[kTileCells + 2 * W + 2];
+  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 2)];
   const DevState& s = db.state[slot];
   if (s.done) return;
-  for (int i = threadIdx.x; i < (W / 2) * 2 * NCO; i += blockDim.x) spoly[i] = dc.poly[i];
+  const PanelParams pp = s.pp;
+  stage_es_tables<W>(ec, s_poly, nullptr);
   __syncthreads();
-  const int variant = s.pp.jacobi;
-  const int64_t n1 = dc.n1, n2 = dc.n2;
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 2 * n2) return;
-  const int rule = idx >= n2 ? 1 : 0;
-  const int64_t g = rule ? idx - n2 : idx;
-  const int64_t l = (g < n2 / 2) ? g : g - n2;
-  double2 out = make_double2(0.0, 0.0);
-  if (l >= -(n1 / 2) && l < n1 - n1 / 2) {
-    const int64_t L = l + n1 / 2;
-    const int* cs = dc.cellstart[variant][rule];
-    const double* pos = dc.pos[variant][rule];
-    const double2* src = rule ? db.src2 : db.src1;
-    const int64_t c0 = L - W / 2 < 0 ? 0 : L - W / 2;
-    const int64_t c1 = L + W / 2 > n1 ? n1 : L + W / 2;
-    const int jlo = cs[c0], jhi = cs[c1];
-    double ar = 0.0, ai = 0.0;
-    for (int j = jlo; j < jhi; ++j) {
-      const double zq = (double)L - pos[j] + 0.5 * W;  // in [0, W]
-      int q = (int)floor(zq);
-      q = q < 0 ? 0 : (q > W - 1 ? W - 1 : q);
-      const double y = zq - (double)q - 0.5;
-      const int qq = q < W / 2 ? q : W - 1 - q;
-      double E, O;
-      es_pair<W>(spoly, qq, y * y, E, O);
-      const double phi = (q < W / 2) ? fma(y, O, E) : fma(-y, O, E);
-      const double2 cj = src[j];
-      ar = fma(cj.x, phi, ar);
-      ai = fma(cj.y, phi, ai);
+  const int64_t n1 = dc.n1, n2 = dc.n2, M = dc.M;
+  const int variant = pp.jacobi;
+  const int ntiles = dc.ntiles[variant];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= ntiles) {
+    // zero padding of the FFT input: indices [n1 - n1/2, n2 - n1/2) of both rules
+    const int64_t npad = n2 - n1;
+    int64_t g = ((int64_t)blockIdx.x - ntiles) * kSpreadThreads + tid;
+    if (g < 2 * npad) {
+      const int rule = g >= npad ? 1 : 0;
+      const int64_t off = rule ? g - npad : g;
+      db.fft[(int64_t)rule * n2 + (n1 - n1 / 2) + off] = make_double2(0.0, 0.0);
     }
-    const double dcv = dc.deconv[l < 0 ? -l : l];
-    out = make_double2(ar * dcv, ai * dcv);
+    return;
   }
-  db.fft[idx] = out;
+  const int2 tl = dc.tiles[variant][blockIdx.x];
+  const int rule = (tl.x >> 30) & 1;
+  const int64_t L0 = (int64_t)(tl.x & 0x3fffffff);
+  const int ncell = tl.y;
+  const int* __restrict__ cs = dc.cellstart[variant][rule];
+  const double* __restrict__ pos = dc.pos[variant][rule];
+  const int64_t c0 = L0 - W / 2 < 0 ? 0 : L0 - W / 2;
+  const int64_t c1 = L0 + ncell + W / 2 > n1 ? n1 : L0 + ncell + W / 2;
+  const int jlo = cs[c0], jhi = cs[c1];
+  const int64_t mr = rule ? 2 * dc.m : dc.m;
+  const int cell = tid & (kTileCells - 1);
+  const int part = tid / kTileCells;
+  constexpr int NPART = kSpreadThreads / kTileCells;
+  double ar = 0.0, ai = 0.0;
+  for (int jb = jlo; jb < jhi; jb += kSpreadThreads) {
+    const int j = jb + tid;
+    const int nb = (jhi - jb) < kSpreadThreads ? (jhi - jb) : kSpreadThreads;
+    if (j < jhi) {
+      // (0) quadrature node, weight, SDF, pre-phase
+      const int64_t sp = j / mr, q = j - sp * mr;
+      const double pa = pp.pa, pb = pp.pb;
+      const double sa = (sp == 0) ? pa : pa + (pb - pa) * ((double)sp / (double)dc.k);
+      const double sb = (sp + 1 == dc.k) ? pb : pa + (pb - pa) * ((double)(sp + 1) / (double)dc.k);
+      const double bmad2 = 0.5 * (sb - sa), bpad2 = 0.5 * (sb + sa);
+      double w, wq;
+      if (pp.jacobi && sp == 0) {  // src/quadrature.jl:61-78
+        const double* no = rule ? dc.jac_no2 : dc.jac_no1;
+        const double* wt = rule ? dc.jac_wt2 : dc.jac_wt1;
+        w = bmad2 * no[q] + bpad2;
+        wq = wt[q] * pow(bmad2, dc.p + 1.0);
+      } else {  // src/quadrature.jl:82-92
+        const double* no = rule ? dc.leg_no2 : dc.leg_no1;
+        const double* wt = rule ? dc.leg_wt2 : dc.leg_wt1;
+        w = bmad2 * no[q] + bpad2;
+        wq = wt[q] * bmad2 * (dc.p == 0.0 ? 1.0 : pow(w, dc.p));
+      }
+      const double f = (dc.sdf_kind == SK_SDF_CALLBACK) ? db.fvals[(rule ? M : 0) + j]
+                                                        : sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, w);
+      const double cj = wq * f;
+      const double P = pos[j];
+      const double u = (P - 0.5 * (double)n1) * dc.delta;
+      const double2 ph = cis_turns_prod(pp.kappa, u);
+      s_c[tid] = make_double2(cj * ph.x, cj * ph.y);
+      // (1) kernel weights of the W cells l0 .. l0+W-1 touched by this source
+      const double tcn = P - 0.5 * W;
+      const double l0d = ceil(tcn);
+      const double y = (l0d - tcn) - 0.5;
+      const double y2 = y * y;
+      s_l0[tid] = (int)((int64_t)l0d - L0);
+      double* wrow = &s_w[tid * (W + 1)];
+#pragma unroll
+      for (int qq = 0; qq < W / 2; ++qq) {
+        double E, O;
+        es_pair<W>(s_poly, qq, y2, E, O);
+        wrow[qq] = fma(y, O, E);
+        wrow[W - 1 - qq] = fma(-y, O, E);
+      }
+    }
+    __syncthreads();
+    // staged sources are sorted, so the sources touching a cell form a contiguous range
+    if (tid < nb) {
+      const int lo_c = (tid == 0) ? -W : s_l0[tid - 1] + 1;
+      int hi_c = s_l0[tid];
+      hi_c = hi_c > kTileCells + W ? kTileCells + W : hi_c;
+      for (int c = lo_c < -W ? -W : lo_c; c <= hi_c; ++c) s_first[c + W] = tid;
+      if (tid == nb - 1)
+        for (int c = (s_l0[tid] + 1 < -W ? -W : s_l0[tid] + 1); c <= kTileCells + W + 1; ++c) s_first[c + W] = nb;
+    }
+    __syncthreads();
+    // (2) gather: lane = cell; wave `part` takes every NPART-th source of the cell's range
+    {
+      const int j0 = s_first[cell - W + 1 + W], j1 = s_first[cell + 1 + W];
+      for (int jj = j0 + part; jj < j1; jj += NPART) {
+        const int rel = cell - s_l0[jj];
+        const double wv = s_w[jj * (W + 1) + rel];
+        const double2 c = s_c[jj];
+        ar = fma(c.x, wv, ar);
+        ai = fma(c.y, wv, ai);
+      }
+    }
+    __syncthreads();
+  }
+  s_red[tid] = make_double2(ar, ai);
+  __syncthreads();
+  if (part == 0) {
+    const int64_t L = L0 + cell;
+    if (cell < ncell) {
+#pragma unroll
+      for (int pidx = 1; pidx < NPART; ++pidx) {
+        ar += s_red[pidx * kTileCells + cell].x;
+        ai += s_red[pidx * kTileCells + cell].y;
+      }
+      const int64_t l = L - n1 / 2;
+      // (-1)^l centres the FFT output (index k + n2/2), so k_interp never wraps around
+      const double dcv = ((l & 1) ? -1.0 : 1.0) * dc.deconv[l < 0 ? -l : l];
+      db.fft[(int64_t)rule * n2 + (l < 0 ? l + n2 : l)] = make_double2(ar * dcv, ai * dcv);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ interpolation core
 
-// Returns F = exp(2 pi i Cx r) * G(v) for both rules: the panel sum sum_j c_j exp(2 pi i w_j r).
+// F = exp(2 pi i Cx r) * G(v) for both rules: the panel sums sum_j c_j exp(2 pi i w_j r).
 template <int W>
-__device__ __forceinline__ void interp_core(const DevConst& dc, const double* __restrict__ spoly,
-                                            const double* __restrict__ scheb, const double2* __restrict__ fft, int nrule,
-                                            double r, double Cx, double r_hi, double tau, double theta_scale,
-                                            double2& F1, double2& F2) {
-  const int64_t n2 = dc.n2;
+__device__ __forceinline__ void interp_core(const DevConst& dc, const double* s_poly, const double* s_cheb,
+                                            const double2* __restrict__ fft, int nrule, double r,
+                                            double Cx, double r_hi, double tau, double theta_scale, double2& F1,
+                                            double2& F2) {
+  const int n2 = (int)dc.n2;
   const double Rc = 0.5 * r_hi;
   const double v = (r - Rc) / Rc;
   const double t = tau * v;
@@ -294,153 +422,136 @@ __device__ __forceinline__ void interp_core(const DevConst& dc, const double* __
   const double k0d = ceil(tcn);
   const double y = (k0d - tcn) - 0.5;
   const double y2 = y * y;
-  long long k0 = (long long)k0d;
+  // the FFT output is centred (see k_spread): tap q sits at index k0 + q + n2/2, no wrap-around
+  const double2* __restrict__ f1 = fft + ((int)k0d + n2 / 2);
+  // kernel weights first (24 VGPRs), then the taps: the compiler batches the independent gathers
   double wt[W];
 #pragma unroll
   for (int q = 0; q < W / 2; ++q) {
     double E, O;
-    es_pair<W>(spoly, q, y2, E, O);
+    es_pair<W>(s_poly, q, y2, E, O);
     wt[q] = fma(y, O, E);
     wt[W - 1 - q] = fma(-y, O, E);
   }
   double h1r = 0, h1i = 0, h2r = 0, h2i = 0;
-  long long kk = k0 < 0 ? k0 + n2 : k0;
 #pragma unroll
   for (int q = 0; q < W; ++q) {
-    const double2 u1 = fft[kk];
-    h1r = fma(u1.x, wt[q], h1r);
-    h1i = fma(u1.y, wt[q], h1i);
+    const double2 a1 = f1[q];
+    h1r = fma(a1.x, wt[q], h1r);
+    h1i = fma(a1.y, wt[q], h1i);
     if (nrule > 1) {
-      const double2 u2 = fft[n2 + kk];
-      h2r = fma(u2.x, wt[q], h2r);
-      h2i = fma(u2.y, wt[q], h2i);
+      const double2 a2 = f1[n2 + q];
+      h2r = fma(a2.x, wt[q], h2r);
+      h2i = fma(a2.y, wt[q], h2i);
     }
-    kk = (kk + 1 == n2) ? 0 : kk + 1;
   }
-  // 1/phi_hat(theta) by Clenshaw in s = 2 (theta/theta_max)^2 - 1
+  // 1/phi_hat(theta) by Clenshaw in s = 2 (theta/theta_max)^2 - 1 (scalar coefficient loads)
   const double th = theta_scale * v / dc.theta_max;
   double sarg = 2.0 * th * th - 1.0;
   sarg = sarg > 1.0 ? 1.0 : sarg;
   double b1 = 0.0, b2 = 0.0;
-  for (int kq = dc.ncheb - 1; kq >= 1; --kq) {
-    const double b0 = fma(2.0 * sarg, b1, scheb[kq] - b2);
+  const double* cheb = s_cheb;
+#pragma unroll
+  for (int kq = 19; kq >= 1; --kq) {  // ncheb == 20 (sk_tables.cpp)
+    const double b0 = fma(2.0 * sarg, b1, cheb[kq] - b2);
     b2 = b1;
     b1 = b0;
   }
-  const double invhat = fma(sarg, b1, scheb[0] - b2);
+  const double invhat = fma(sarg, b1, cheb[0] - b2);
   const double2 ph = cis_turns_prod(Cx, r);
   h1r *= invhat; h1i *= invhat; h2r *= invhat; h2i *= invhat;
   F1 = make_double2(h1r * ph.x - h1i * ph.y, h1r * ph.y + h1i * ph.x);
   F2 = make_double2(h2r * ph.x - h2i * ph.y, h2r * ph.y + h2i * ph.x);
 }
 
+// One evaluation of the current (sub)panel at the active lags.  Per lag: read r and the confirmed
+// running sums, write the optimistic sums (other acc buffer) and the optimistic final outputs
+// ks = K-sum (src/quadrature.jl:261, src/adaptive.jl:163), errs = err-sum + 2*trunc_err
+// (src/quadrature.jl:262, src/adaptive.jl:164,194).  A lag's outputs become final when it retires;
+// until then every later evaluation overwrites them.  Per workgroup: max |I2-I1|, NaN flags and the
+// highest lag failing the convergence predicate (src/adaptive.jl:183-198, :231-233), all
+// speculative on this panel being accepted -- k_advance decides.
 template <int W>
-__global__ void __launch_bounds__(256) k_interp(DevConst dc, DevBuffers db, int slot, long long n) {
-  constexpr int NCO = W / 2 + 2;
-  __shared__ double spoly[(W / 2) * 2 * NCO];
-  __shared__ double scheb[kMaxCheb];
-  __shared__ unsigned long long smax[4];
+__global__ void __launch_bounds__(256, 4) k_interp(DevConst dc, EsConst ec, DevBuffers db, int slot, long long n) {
+  __shared__ double smax[4];
+  __shared__ unsigned int shi[4];
   __shared__ int sflag[2];
-  DevState& s = db.state[slot];
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  // deferred 2*trunc_err for the lags retired by the previous outer panel (src/adaptive.jl:194)
-  if (s.retire_pending && i >= s.hi && i < s.hi_prev) db.errs[i] += db.tmpE[i];
+  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 2)];
+  __shared__ double s_cheb[20];
+  // read the needed state fields before any store so that the loads stay scalar
+  const DevState& s = db.state[slot];
   if (s.done) return;
+  const PanelParams pp = s.pp;
+  const TailScalars tail = s.tail;
+  const int conf = s.conf, has_acc = s.has_acc, pc = s.pc, p_valid = s.p_valid, stack_len = s.stack_len;
+  const double T2 = dc.tol * s.k0abs * 0.5;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long ix1 = s.ix1, hi = s.hi;
   if ((long long)blockIdx.x * blockDim.x >= hi) return;
-  for (int t = threadIdx.x; t < (W / 2) * 2 * NCO; t += blockDim.x) spoly[t] = dc.poly[t];
-  for (int t = threadIdx.x; t < dc.ncheb; t += blockDim.x) scheb[t] = dc.cheb[t];
   if (threadIdx.x < 2) sflag[threadIdx.x] = 0;
+  stage_es_tables<W>(ec, s_poly, s_cheb);
   __syncthreads();
   double e = 0.0;
   int n1f = 0, n2f = 0;
+  unsigned int unconv = 0u;
   if (i >= ix1 && i < hi) {
     const double r = db.xs[i];
+    const int c = conf, o = conf ^ 1;
+    double Ck = 0.0, Ce = 0.0, Pk = 0.0;
+    if (has_acc) {
+      Ck = db.accK[c][i];
+      Ce = db.accE[c][i];
+    }
+    if (p_valid) Pk = db.P[pc][i];
     double2 F1, F2;
-    interp_core<W>(dc, spoly, scheb, db.fft, 2, r, s.pp.Cx, s.pp.r_hi, s.pp.tau, s.pp.theta_scale, F1, F2);
-    double scale = dc.c;  // src/quadrature.jl:250-255
-    double I1 = (dc.derivative ? F1.y : F1.x) * scale;
-    double I2 = (dc.derivative ? F2.y : F2.x) * scale;
+    interp_core<W>(dc, s_poly, s_cheb, db.fft, 2, r, pp.Cx, pp.r_hi, pp.tau, pp.theta_scale, F1, F2);
+    const double scale = dc.c;  // src/quadrature.jl:250-255 (dim == 1)
+    const double I1 = (dc.derivative ? F1.y : F1.x) * scale;
+    const double I2 = (dc.derivative ? F2.y : F2.x) * scale;
     e = fabs(I2 - I1);
     n1f = isnan(I1);
     n2f = isnan(I2);
-    db.tmpI[i] = I2;
-    db.tmpE[i] = e;
+    const double Sk = Ck + I2, Se = Ce + e;
+    db.accK[o][i] = Sk;
+    db.accE[o][i] = Se;
+    const double pk = Pk + I2;
+    double te2 = 0.0;
+    if (stack_len == 0) {
+      const int crit = tail.crit;
+      const double te = (crit == SK_CRIT_PANEL) ? 0.0 : trunc_est(tail, r, dc.dim);
+      const bool conv = (crit == SK_CRIT_PANEL || te < T2) && (crit == SK_CRIT_TAILS || fabs(pk) < T2);
+      unconv = conv ? 0u : (unsigned int)(i + 1);
+      te2 = 2.0 * te;
+    } else {
+      db.P[pc ^ 1][i] = pk;  // needed by the later sub-panels of this outer panel if accepted
+    }
+    db.ks[i] = Sk;
+    db.errs[i] = Se + te2;
   }
-  // block max over the bit patterns (e >= 0 or NaN; NaN patterns compare above +inf)
-  unsigned long long bits = (unsigned long long)__double_as_longlong(e);
+  // workgroup reductions; NaNs are carried by the flags (fmax drops them)
+  double emax = e;
   for (int off = 32; off > 0; off >>= 1) {
-    unsigned long long o = __shfl_xor(bits, off, 64);
-    bits = o > bits ? o : bits;
+    emax = fmax(emax, __shfl_xor(emax, off, 64));
+    const unsigned int o2 = __shfl_xor(unconv, off, 64);
+    unconv = o2 > unconv ? o2 : unconv;
   }
   if (__any(n1f) && (threadIdx.x & 63) == 0) atomicOr(&sflag[0], 1);
   if (__any(n2f) && (threadIdx.x & 63) == 0) atomicOr(&sflag[1], 1);
-  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = bits;
+  if ((threadIdx.x & 63) == 0) {
+    smax[threadIdx.x >> 6] = emax;
+    shi[threadIdx.x >> 6] = unconv;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned long long b = smax[0];
-    for (int w2 = 1; w2 < (int)(blockDim.x >> 6); ++w2) b = smax[w2] > b ? smax[w2] : b;
-    if (b) atomicMax(&s.max_err_bits, b);
-    if (sflag[0]) atomicOr(&s.nan1, 1);
-    if (sflag[1]) atomicOr(&s.nan2, 1);
-  }
-}
-
-// ------------------------------------------------------------------ k_accum
-
-__global__ void __launch_bounds__(256) k_accum(DevConst dc, DevBuffers db, int slot, long long n) {
-  DevState& s = db.state[slot];
-  if (s.done) return;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long ix1 = s.ix1, hi = s.hi;
-  if ((long long)blockIdx.x * blockDim.x >= hi) return;
-  const bool accept = step_accept(s, dc.tol);
-  if (!accept) return;
-  const bool outer_done = (s.stack_len == 0);
-  bool unconv = false;
-  if (i >= ix1 && i < hi) {
-    double pk = db.P[i] + db.tmpI[i];
-    double pe = db.E[i] + db.tmpE[i];
-    if (!outer_done) {
-      db.P[i] = pk;
-      db.E[i] = pe;
-    } else {
-      db.P[i] = 0.0;
-      db.E[i] = 0.0;
-      db.ks[i] += pk;    // src/adaptive.jl:163-164
-      db.errs[i] += pe;
-      int crit = s.crit;
-      double tc = 0.0, td = 0.0;
-      if (crit != SK_CRIT_PANEL) {
-        tail_fit(dc, s.b, s.fb, tc, td);
-        if (isnan(tc) || isnan(td)) crit = SK_CRIT_PANEL;  // src/adaptive.jl:170-175
-      }
-      const double T2 = dc.tol * s.k0abs * 0.5;
-      const double te = (crit == SK_CRIT_PANEL) ? 0.0 : trunc_est(s.b, db.xs[i], tc, td, dc.dim);
-      const bool conv = (crit == SK_CRIT_PANEL || te < T2) && (crit == SK_CRIT_TAILS || fabs(pk) < T2);
-      db.tmpE[i] = 2.0 * te;
-      unconv = !conv;
+    double b = smax[0];
+    unsigned int h = shi[0];
+    for (int w2 = 1; w2 < (int)(blockDim.x >> 6); ++w2) {
+      b = fmax(b, smax[w2]);
+      h = shi[w2] > h ? shi[w2] : h;
     }
-  }
-  if (outer_done) {
-    // highest unconverged index + 1, wave-reduced then one atomic per wave
-    unsigned long long v = unconv ? (unsigned long long)(i + 1) : 0ull;
-    for (int off = 32; off > 0; off >>= 1) {
-      unsigned long long o = __shfl_xor(v, off, 64);
-      v = o > v ? o : v;
-    }
-    if ((threadIdx.x & 63) == 0 && v) atomicMax(&s.hi_new, v);
-  }
-}
-
-__global__ void __launch_bounds__(256) k_final(DevConst dc, DevBuffers db, int slot, long long n) {
-  const DevState& s = db.state[slot];
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (s.done && s.retire_pending && i >= s.hi && i < s.hi_prev) db.errs[i] += db.tmpE[i];
-  if (s.done == 1 && i == 0 && s.ix1 == 1) {  // src/adaptive.jl:132-146
-    db.ks[0] = s.ks0;
-    db.errs[0] = __builtin_nan("");
+    db.blk_max[blockIdx.x] = b;
+    db.blk_hi[blockIdx.x] = h;
+    db.blk_nan[blockIdx.x] = sflag[0] | (sflag[1] << 1);
   }
 }
 
@@ -451,17 +562,11 @@ static inline unsigned nblk(long long n, int bs) { return (unsigned)((n + bs - 1
 void launch_init(const DevConst& dc, const DevBuffers& db, long long n, double k0, double ks0, hipStream_t st) {
   hipLaunchKernelGGL(k_init, dim3(1), dim3(1), 0, st, dc, db, n, k0, ks0);
 }
-void launch_gen(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st) {
-  hipLaunchKernelGGL(k_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, slot);
+void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st) {
+  hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, st, dc, db, slot);
 }
 void launch_advance(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st) {
-  hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, dc, db, slot);
-}
-void launch_accum(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st) {
-  hipLaunchKernelGGL(k_accum, dim3(nblk(n, 256)), dim3(256), 0, st, dc, db, slot, n);
-}
-void launch_final(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st) {
-  hipLaunchKernelGGL(k_final, dim3(nblk(n, 256)), dim3(256), 0, st, dc, db, slot, n);
+  hipLaunchKernelGGL(k_advance, dim3(1), dim3(256), 0, st, dc, db, slot);
 }
 
 #define SK_DISPATCH_W(w, CALL) \
@@ -475,11 +580,15 @@ void launch_final(const DevConst& dc, const DevBuffers& db, int slot, long long 
     default: { constexpr int W = 16; CALL; } break; \
   }
 
-void launch_spread(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st) {
-  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_spread<W>, dim3(nblk(2 * dc.n2, 256)), dim3(256), 0, st, dc, db, slot));
+void launch_spread(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, hipStream_t st) {
+  // both variants have their own work list; launch for the longer one (extra blocks zero-pad or idle)
+  const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
+  const unsigned padblk = nblk(2 * (dc.n2 - dc.n1), kSpreadThreads);
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_spread<W>, dim3(tiles + padblk), dim3(kSpreadThreads), 0, st, dc, ec, db,
+                                         slot));
 }
-void launch_interp(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st) {
-  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_interp<W>, dim3(nblk(n, 256)), dim3(256), 0, st, dc, db, slot, n));
+void launch_interp(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, long long n, hipStream_t st) {
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_interp<W>, dim3(nblk(n, 256)), dim3(256), 0, st, dc, ec, db, slot, n));
 }
 
 // ------------------------------------------------------------------ seam kernels (sk_panel_sums)
@@ -517,26 +626,24 @@ __global__ void k_seam_deconv(DevConst dc, double2* fft) {
   if (g >= dc.n2) return;
   const int64_t l = (g < dc.n2 / 2) ? g : g - dc.n2;
   if (l >= -(dc.n1 / 2) && l < dc.n1 - dc.n1 / 2) {
-    const double d = dc.deconv[l < 0 ? -l : l];
+    const double d = ((l & 1) ? -1.0 : 1.0) * dc.deconv[l < 0 ? -l : l];
     fft[g].x *= d;
     fft[g].y *= d;
   }
 }
 
 template <int W>
-__global__ void __launch_bounds__(256) k_seam_interp(DevConst dc, const double2* fft, const double* xs, int64_t n,
+__global__ void __launch_bounds__(256) k_seam_interp(DevConst dc, EsConst ec, const double2* fft, const double* xs, int64_t n,
                                                       double Cx, double r_hi, double tau, double theta_scale,
                                                       double* out_re, double* out_im) {
-  constexpr int NCO = W / 2 + 2;
-  __shared__ double spoly[(W / 2) * 2 * NCO];
-  __shared__ double scheb[kMaxCheb];
-  for (int t = threadIdx.x; t < (W / 2) * 2 * NCO; t += blockDim.x) spoly[t] = dc.poly[t];
-  for (int t = threadIdx.x; t < dc.ncheb; t += blockDim.x) scheb[t] = dc.cheb[t];
+  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 2)];
+  __shared__ double s_cheb[20];
+  stage_es_tables<W>(ec, s_poly, s_cheb);
   __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double2 F1, F2;
-  interp_core<W>(dc, spoly, scheb, fft, 1, xs[i], Cx, r_hi, tau, theta_scale, F1, F2);
+  interp_core<W>(dc, s_poly, s_cheb, fft, 1, xs[i], Cx, r_hi, tau, theta_scale, F1, F2);
   out_re[i] = F1.x;
   out_im[i] = F1.y;
 }
@@ -576,9 +683,9 @@ void launch_seam_spread(const DevConst& dc, const double* nodes, const double* c
 void launch_seam_deconv(const DevConst& dc, double2* fft, hipStream_t st) {
   hipLaunchKernelGGL(k_seam_deconv, dim3(nblk(dc.n2, 256)), dim3(256), 0, st, dc, fft);
 }
-void launch_seam_interp(const DevConst& dc, const double2* fft, const double* xs, int64_t n, double Cx, double r_hi,
+void launch_seam_interp(const DevConst& dc, const EsConst& ec, const double2* fft, const double* xs, int64_t n, double Cx, double r_hi,
                         double tau, double theta_scale, double* out_re, double* out_im, hipStream_t st) {
-  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_seam_interp<W>, dim3(nblk(n, 256)), dim3(256), 0, st, dc, fft, xs, n, Cx,
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_seam_interp<W>, dim3(nblk(n, 256)), dim3(256), 0, st, dc, ec, fft, xs, n, Cx,
                                          r_hi, tau, theta_scale, out_re, out_im));
 }
 void launch_direct(const double* nodes, const double* coef, int64_t M, const double* xs, int64_t n, double* out_re,
