@@ -142,8 +142,10 @@ def main():
         items = v["active_items"] / v["launches"]
         if k in alg_bytes:
             b = alg_bytes[k] * items
+        elif k == "gen":
+            b = 48.0 * M + 48.0 * M  # read node + weight of both rules (M + 2M) x (8 + 8), write 3M complex strengths
         elif k == "spread":
-            b = 48.0 * M + 16.0 * items  # nodes + weights of both rules (M + 2M) x (8 + 8); write two complex grids
+            b = 48.0 * M + 24.0 * M + 16.0 * items  # read 3M complex strengths + positions; write two complex grids
         elif k == "fft":
             b = 2 * 16.0 * items  # read + write both grids once
         else:

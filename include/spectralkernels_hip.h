@@ -131,11 +131,11 @@ int sk_last_stats(const sk_config* cfg, sk_stats* out);
 /* Per-kernel device timing of the hot path, measured with HIP events on the stream the kernels
  * are launched on.  Off by default (events add host overhead); when enabled every launch of the
  * next sk_kernel_values* calls is bracketed by two events.  Kernel ids: */
-enum { SK_K_SPREAD = 0, SK_K_FFT = 1, SK_K_INTERP = 2, SK_K_ADVANCE = 3, SK_K_COUNT = 4 };
+enum { SK_K_GEN = 0, SK_K_SPREAD = 1, SK_K_FFT = 2, SK_K_INTERP = 3, SK_K_ADVANCE = 4, SK_K_COUNT = 5 };
 typedef struct {
   double total_ms[SK_K_COUNT]; /* summed over the launches of the last call */
   int64_t launches[SK_K_COUNT];
-  int64_t active_items[SK_K_COUNT]; /* summed work items: grid points (spread, fft), active lags (interp), panels (advance) */
+  int64_t active_items[SK_K_COUNT]; /* summed work items: nodes (gen), grid points (spread, fft), active lags (interp), panels (advance) */
 } sk_kernel_times;
 int sk_profile_enable(sk_config* cfg, int on);
 int sk_profile_read(const sk_config* cfg, sk_kernel_times* out);

@@ -26,11 +26,11 @@ class Stats(C.Structure):
                 ("last_b", C.c_double)]
 
 
-K_NAMES = ["spread", "fft", "interp", "advance"]
+K_NAMES = ["gen", "spread", "fft", "interp", "advance"]
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("total_ms", C.c_double * 4), ("launches", C.c_int64 * 4), ("active_items", C.c_int64 * 4)]
+    _fields_ = [("total_ms", C.c_double * 5), ("launches", C.c_int64 * 5), ("active_items", C.c_int64 * 5)]
 
 
 _lib = None

@@ -4,6 +4,7 @@
 #include <rocfft/rocfft.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <mutex>
@@ -177,10 +178,10 @@ static void build_positions(const sk_config* cfg, int variant, int rule, std::ve
 
 // Spread work list of one variant: tiles of <= 64 cells holding <= ~256 touching sources where the
 // node density allows it (Gauss nodes cluster like 1/m^2 at every sub-panel edge), heaviest first.
-static void build_tiles(const sk_config* cfg, const std::vector<int> cs[2], std::vector<int2>& tiles) {
+static void build_tiles(const sk_config* cfg, const std::vector<int> cs[2], std::vector<int4>& tiles) {
   const int64_t n1 = cfg->dc.n1;
   const int W = cfg->dc.w;
-  struct T { int key, start, len, cnt; };
+  struct T { int key, start, len, cnt, jlo, jhi; };
   std::vector<T> all;
   for (int rule = 0; rule < 2; ++rule) {
     const std::vector<int>& c = cs[rule];
@@ -190,15 +191,17 @@ static void build_tiles(const sk_config* cfg, const std::vector<int> cs[2], std:
     };
     int64_t start = 0;
     while (start < n1) {
-      int64_t end = start + 8 > n1 ? n1 : start + 8;
+      int64_t end = start + 4 > n1 ? n1 : start + 4;
       while (end < n1 && end - start < 64 && touching(start, end + 1) <= 256) ++end;
-      all.push_back({(rule << 30) | (int)start, (int)start, (int)(end - start), touching(start, end)});
+      const int64_t lo = start - W / 2 < 0 ? 0 : start - W / 2, hi = end + W / 2 > n1 ? n1 : end + W / 2;
+      all.push_back({(rule << 30) | (int)start, (int)start, (int)(end - start), touching(start, end), c[(size_t)lo],
+                     c[(size_t)hi]});
       start = end;
     }
   }
   std::stable_sort(all.begin(), all.end(), [](const T& a, const T& b) { return a.cnt > b.cnt; });
   tiles.clear();
-  for (const T& t : all) tiles.push_back(make_int2(t.key, t.len));
+  for (const T& t : all) tiles.push_back(make_int4(t.key, t.len, t.jlo, t.jhi));
 }
 
 static int ensure_ws(sk_config* cfg, size_t bytes) {
@@ -325,6 +328,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     }
     for (int r = 0; r < R; ++r) {
       if (cb) launch_tail(cfg->dc, db, slot, st);
+      { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, slot, st); }
       { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->ec, db, slot, st); }
       {
         EvScope e(cfg, st, SK_K_FFT);
@@ -367,6 +371,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         cfg->ktimes.launches[r.kid] += 1;
       }
     }
+    cfg->ktimes.active_items[SK_K_GEN] = 3 * cfg->M * hs->n_panels;
     cfg->ktimes.active_items[SK_K_SPREAD] = 2 * cfg->dc.n2 * hs->n_panels;
     cfg->ktimes.active_items[SK_K_FFT] = 2 * cfg->dc.n2 * hs->n_panels;
     cfg->ktimes.active_items[SK_K_INTERP] = hs->sum_active;
@@ -374,6 +379,13 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     cfg->ev_recs.clear();
     cfg->ev_used = 0;
   }
+#ifdef SK_STAMPS
+  if (const char* f = getenv("SK_STAMP_FILE")) {
+    std::vector<unsigned long long> h(8 * 8192);
+    (void)hipMemcpy(h.data(), db.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen(f, "wb")) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); }
+  }
+#endif
   if (hs->done < 0) return fail(-hs->done, status_message(-hs->done));
   return SK_OK;
 }
@@ -548,7 +560,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
       UP(pos, dc.pos[variant][rule]);
       UP(cs2[rule], dc.cellstart[variant][rule]);
     }
-    std::vector<int2> tiles;
+    std::vector<int4> tiles;
     build_tiles(cfg, cs2, tiles);
     UP(tiles, dc.tiles[variant]);
     dc.ntiles[variant] = (int)tiles.size();
@@ -562,9 +574,12 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     if (rc) { sk_config_destroy(cfg); return rc; }         \
   } while (0)
   DA(2, db.state); DA(kStackCap, db.stack); DA(kTraceCap, db.trace);
-  DA((size_t)2 * dc.n2, db.fft);
+  DA((size_t)3 * cfg->M, db.src); DA((size_t)2 * dc.n2, db.fft);
   DA((size_t)3 * cfg->M, cfg->d_fvals);
   DA(2, cfg->d_flags);
+#ifdef SK_STAMPS
+  DA(8 * 8192, db.stamps);
+#endif
 #undef DA
   if (hipHostMalloc((void**)&cfg->h_state, sizeof(DevState)) != hipSuccess ||
       hipHostMalloc((void**)&cfg->h_flags, 2 * sizeof(int)) != hipSuccess ||

@@ -29,9 +29,9 @@ struct DevConst {
   const double* pos[2][2];      // [variant][rule] source positions in grid units, P_j in [w/2, n1-w/2]
   const int* cellstart[2][2];   // [variant][rule] first source with floor(P_j) >= cell, n1+1 entries
   const double* deconv;         // n1/2+1 values of 1/phi_hat(2 pi l/n2)
-  // spread work list per variant: (rule << 30 | first cell, cells <= 64) sorted by decreasing
-  // source count, so that the dense sub-panel-edge tiles start first
-  const int2* tiles[2];
+  // spread work list per variant: {rule << 30 | first cell, cells <= 64, first source, end source}
+  // sorted by decreasing source count, so that the dense sub-panel-edge tiles start first
+  const int4* tiles[2];
   int ntiles[2];
 };
 
@@ -87,6 +87,7 @@ struct DevBuffers {
   DevState* state;          // 2 slots (ping-pong)
   double2* stack;           // kStackCap (a,b) pairs
   TraceRec* trace;          // kTraceCap
+  double2* src;             // 3M pre-phased source strengths (rule 1: M, rule 2: 2M)
   double2* fft;             // 2 x n2 complex (rule 1, rule 2)
   const double* fvals;      // callback mode: S(omega_j) for rule 1 (M) then rule 2 (2M)
   const double* xs;         // sorted unique lags
@@ -96,11 +97,13 @@ struct DevBuffers {
   // per-workgroup partial reductions of k_interp (no same-address atomics): max |I2-I1| bits,
   // highest unconverged lag + 1, NaN flags (bit 0: I1, bit 1: I2)
   double* blk_max; unsigned int* blk_hi; int* blk_nan;
+  unsigned long long* stamps;  // diagnostic builds only (SK_STAMPS): 8 words per k_spread workgroup
 };
 
 // launchers (sk_kernels.hip)
 void launch_init(const DevConst& dc, const DevBuffers& db, long long n, double k0, double ks0, hipStream_t st);
 void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);  // callback SDFs only
+void launch_gen(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);
 void launch_spread(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, hipStream_t st);
 void launch_interp(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, long long n, hipStream_t st);
 void launch_advance(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);

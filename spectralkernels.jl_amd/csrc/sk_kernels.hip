@@ -1,8 +1,8 @@
 // sk_kernels.hip -- gfx950 kernels of the kernel_values hot path.
 //
 // One (sub)panel evaluation ("step") is
-//   k_spread  nodes, SDF, Gauss weights, pre-phase (src/quadrature.jl:49-95 updatequadbufs!) staged in
-//             LDS, then tile-wise ES spreading + deconvolution (type-3 NUFFT, replaces finufft1d3,
+//   k_gen     nodes, SDF, Gauss weights, pre-phase (src/quadrature.jl:49-95 updatequadbufs!)
+//   k_spread  tile-wise ES spreading through LDS + deconvolution (type-3 NUFFT, replaces finufft1d3,
 //   rocFFT    length n2, batch 2 (m- and 2m-rule)         src/utils.jl:10 / src/quadrature.jl:109-110)
 //   k_interp  applies the previous step's pending sums (src/quadrature.jl:261-262, src/adaptive.jl:
 //             163-164, :194), interpolates at the active lags, post-phase, scaling, |I2-I1| and its
@@ -272,27 +272,60 @@ __device__ __forceinline__ void stage_es_tables(const EsConst& ec, double* s_pol
 constexpr int kTileCells = 64;   // spread-grid cells per workgroup
 constexpr int kSpreadThreads = 256;
 
-// One workgroup owns kTileCells consecutive cells of one rule's spread grid.  Per batch of 256
-// sources whose support touches the tile: (0) node, SDF value, Gauss weight and pre-phase of the
-// source (updatequadbufs!, src/quadrature.jl:49-95) are computed in registers and staged in LDS,
-// (1) its W kernel weights are staged in LDS, (2) every cell gathers from the staged batch in a
-// fixed order (deterministic, no atomics).  The tile is deconvolved and written in FFT order.
+// k_gen: one thread per quadrature node of the current (sub)panel, both rules: node, SDF value,
+// Gauss weight (updatequadbufs!, src/quadrature.jl:49-95) and the type-3 pre-phase; writes the
+// complex source strengths c'_j (rule 1: M entries, then rule 2: 2M entries).
+__global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int slot) {
+  const DevState& s = db.state[slot];
+  if (s.done) return;
+  const PanelParams pp = s.pp;
+  const int64_t M = dc.M;
+  const int64_t jg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (jg >= 3 * M) return;
+  const int rule = jg < M ? 0 : 1;
+  const int64_t j = rule ? jg - M : jg;
+  const int64_t mr = rule ? 2 * dc.m : dc.m;
+  const int64_t sp = j / mr, q = j - sp * mr;
+  const double pa = pp.pa, pb = pp.pb;
+  const double sa = (sp == 0) ? pa : pa + (pb - pa) * ((double)sp / (double)dc.k);
+  const double sb = (sp + 1 == dc.k) ? pb : pa + (pb - pa) * ((double)(sp + 1) / (double)dc.k);
+  const double bmad2 = 0.5 * (sb - sa), bpad2 = 0.5 * (sb + sa);
+  double w, wq;
+  if (pp.jacobi && sp == 0) {  // src/quadrature.jl:61-78
+    const double* no = rule ? dc.jac_no2 : dc.jac_no1;
+    const double* wt = rule ? dc.jac_wt2 : dc.jac_wt1;
+    w = bmad2 * no[q] + bpad2;
+    wq = wt[q] * pow(bmad2, dc.p + 1.0);
+  } else {  // src/quadrature.jl:82-92
+    const double* no = rule ? dc.leg_no2 : dc.leg_no1;
+    const double* wt = rule ? dc.leg_wt2 : dc.leg_wt1;
+    w = bmad2 * no[q] + bpad2;
+    wq = wt[q] * bmad2 * (dc.p == 0.0 ? 1.0 : pow(w, dc.p));
+  }
+  const double f = (dc.sdf_kind == SK_SDF_CALLBACK) ? db.fvals[jg] : sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, w);
+  const double cj = wq * f;
+  const double P = dc.pos[pp.jacobi][rule][j];
+  const double u = (P - 0.5 * (double)dc.n1) * dc.delta;
+  const double2 ph = cis_turns_prod(pp.kappa, u);
+  db.src[jg] = make_double2(cj * ph.x, cj * ph.y);
+}
+
+// k_spread: one workgroup owns <= kTileCells consecutive cells of one rule's spread grid.  Per batch
+// of 256 sources whose support touches the tile, every thread stages one source in LDS (strength,
+// first cell, its W kernel weights); then every cell gathers from the staged batch in a fixed order
+// (lane = cell, the 4 waves split the cell's contiguous source range; deterministic, no atomics).
+// The tile is deconvolved, centred with (-1)^l and written in FFT order.
 template <int W>
 __global__ void __launch_bounds__(kSpreadThreads) k_spread(DevConst dc, EsConst ec, DevBuffers db, int slot) {
   __shared__ double s_w[kSpreadThreads * (W + 1)];
   __shared__ double2 s_c[kSpreadThreads];
   __shared__ int s_l0[kSpreadThreads];
   __shared__ double2 s_red[kSpreadThreads];
-  // s_first[c + W]: first staged source whose first cell l0 is >= c (c relative to the tile, -W..TC+W)
-  __shared__ int s_first[kTileCells + 2 * W + 2];
   __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 2)];
   const DevState& s = db.state[slot];
   if (s.done) return;
-  const PanelParams pp = s.pp;
-  stage_es_tables<W>(ec, s_poly, nullptr);
-  __syncthreads();
-  const int64_t n1 = dc.n1, n2 = dc.n2, M = dc.M;
-  const int variant = pp.jacobi;
+  const int variant = s.pp.jacobi;
+  const int64_t n1 = dc.n1, n2 = dc.n2;
   const int ntiles = dc.ntiles[variant];
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= ntiles) {
@@ -306,55 +339,61 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread(DevConst dc, EsConst 
     }
     return;
   }
-  const int2 tl = dc.tiles[variant][blockIdx.x];
+#ifdef SK_STAMPS
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#endif
+  const int4 tl = dc.tiles[variant][blockIdx.x];  // {rule<<30 | first cell, cells, first source, end source}
   const int rule = (tl.x >> 30) & 1;
-  const int64_t L0 = (int64_t)(tl.x & 0x3fffffff);
+  const int L0 = tl.x & 0x3fffffff;
   const int ncell = tl.y;
+  const int jlo = tl.z, jhi = tl.w;
   const int* __restrict__ cs = dc.cellstart[variant][rule];
   const double* __restrict__ pos = dc.pos[variant][rule];
-  const int64_t c0 = L0 - W / 2 < 0 ? 0 : L0 - W / 2;
-  const int64_t c1 = L0 + ncell + W / 2 > n1 ? n1 : L0 + ncell + W / 2;
-  const int jlo = cs[c0], jhi = cs[c1];
-  const int64_t mr = rule ? 2 * dc.m : dc.m;
-  const int cell = tid & (kTileCells - 1);
-  const int part = tid / kTileCells;
-  constexpr int NPART = kSpreadThreads / kTileCells;
+  const double2* __restrict__ src = db.src + (rule ? dc.M : 0);
+  // first batch's loads are issued before the table staging barrier
+  double P_next = 0.0;
+  double2 c_next = make_double2(0.0, 0.0);
+  if (jlo + tid < jhi) {
+    P_next = pos[jlo + tid];
+    c_next = src[jlo + tid];
+  }
+  // lane mapping: tiles at the sub-panel edges have few cells but many sources, so the 64 lanes of
+  // a wave are split as (cell, sub): `spl` lanes share one cell and take strided sources
+  int c2 = 64;
+  while (c2 / 2 >= ncell && c2 > 1) c2 >>= 1;  // smallest power of two >= ncell (<= 64)
+  const int spl = 64 / c2;
+  const int lane = tid & 63;
+  const int part = tid >> 6;
+  constexpr int NPART = kSpreadThreads / 64;
+  const int cell = lane / spl, sub = lane - cell * spl;
+  // sources touching cell L have floor(P_j) in [L - W/2, L + W/2): a contiguous range of the sorted list
+  int J0 = 0, J1 = 0;
+  if (cell < ncell) {
+    const int L = L0 + cell;
+    J0 = cs[L - W / 2 < 0 ? 0 : L - W / 2];
+    J1 = cs[L + W / 2 > (int)n1 ? (int)n1 : L + W / 2];
+  }
+  stage_es_tables<W>(ec, s_poly, nullptr);
+  __syncthreads();
+#ifdef SK_STAMPS
+  t1 = __builtin_amdgcn_s_memtime();
+#endif
   double ar = 0.0, ai = 0.0;
   for (int jb = jlo; jb < jhi; jb += kSpreadThreads) {
     const int j = jb + tid;
     const int nb = (jhi - jb) < kSpreadThreads ? (jhi - jb) : kSpreadThreads;
     if (j < jhi) {
-      // (0) quadrature node, weight, SDF, pre-phase
-      const int64_t sp = j / mr, q = j - sp * mr;
-      const double pa = pp.pa, pb = pp.pb;
-      const double sa = (sp == 0) ? pa : pa + (pb - pa) * ((double)sp / (double)dc.k);
-      const double sb = (sp + 1 == dc.k) ? pb : pa + (pb - pa) * ((double)(sp + 1) / (double)dc.k);
-      const double bmad2 = 0.5 * (sb - sa), bpad2 = 0.5 * (sb + sa);
-      double w, wq;
-      if (pp.jacobi && sp == 0) {  // src/quadrature.jl:61-78
-        const double* no = rule ? dc.jac_no2 : dc.jac_no1;
-        const double* wt = rule ? dc.jac_wt2 : dc.jac_wt1;
-        w = bmad2 * no[q] + bpad2;
-        wq = wt[q] * pow(bmad2, dc.p + 1.0);
-      } else {  // src/quadrature.jl:82-92
-        const double* no = rule ? dc.leg_no2 : dc.leg_no1;
-        const double* wt = rule ? dc.leg_wt2 : dc.leg_wt1;
-        w = bmad2 * no[q] + bpad2;
-        wq = wt[q] * bmad2 * (dc.p == 0.0 ? 1.0 : pow(w, dc.p));
+      const double P = P_next;
+      s_c[tid] = c_next;
+      if (j + kSpreadThreads < jhi) {  // prefetch the next batch
+        P_next = pos[j + kSpreadThreads];
+        c_next = src[j + kSpreadThreads];
       }
-      const double f = (dc.sdf_kind == SK_SDF_CALLBACK) ? db.fvals[(rule ? M : 0) + j]
-                                                        : sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, w);
-      const double cj = wq * f;
-      const double P = pos[j];
-      const double u = (P - 0.5 * (double)n1) * dc.delta;
-      const double2 ph = cis_turns_prod(pp.kappa, u);
-      s_c[tid] = make_double2(cj * ph.x, cj * ph.y);
-      // (1) kernel weights of the W cells l0 .. l0+W-1 touched by this source
       const double tcn = P - 0.5 * W;
       const double l0d = ceil(tcn);
       const double y = (l0d - tcn) - 0.5;
       const double y2 = y * y;
-      s_l0[tid] = (int)((int64_t)l0d - L0);
+      s_l0[tid] = (int)l0d - L0;
       double* wrow = &s_w[tid * (W + 1)];
 #pragma unroll
       for (int qq = 0; qq < W / 2; ++qq) {
@@ -365,44 +404,52 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread(DevConst dc, EsConst 
       }
     }
     __syncthreads();
-    // staged sources are sorted, so the sources touching a cell form a contiguous range
-    if (tid < nb) {
-      const int lo_c = (tid == 0) ? -W : s_l0[tid - 1] + 1;
-      int hi_c = s_l0[tid];
-      hi_c = hi_c > kTileCells + W ? kTileCells + W : hi_c;
-      for (int c = lo_c < -W ? -W : lo_c; c <= hi_c; ++c) s_first[c + W] = tid;
-      if (tid == nb - 1)
-        for (int c = (s_l0[tid] + 1 < -W ? -W : s_l0[tid] + 1); c <= kTileCells + W + 1; ++c) s_first[c + W] = nb;
-    }
-    __syncthreads();
-    // (2) gather: lane = cell; wave `part` takes every NPART-th source of the cell's range
+#ifdef SK_STAMPS
+    if (jb == jlo) t2 = __builtin_amdgcn_s_memtime();
+#endif
     {
-      const int j0 = s_first[cell - W + 1 + W], j1 = s_first[cell + 1 + W];
-      for (int jj = j0 + part; jj < j1; jj += NPART) {
+      const int j0 = (J0 > jb ? J0 : jb) - jb;
+      const int j1 = (J1 < jb + nb ? J1 : jb + nb) - jb;
+      for (int jj = j0 + part * spl + sub; jj < j1; jj += NPART * spl) {
         const int rel = cell - s_l0[jj];
-        const double wv = s_w[jj * (W + 1) + rel];
-        const double2 c = s_c[jj];
-        ar = fma(c.x, wv, ar);
-        ai = fma(c.y, wv, ai);
+        if (rel >= 0 && rel < W) {
+          const double wv = s_w[jj * (W + 1) + rel];
+          const double2 c = s_c[jj];
+          ar = fma(c.x, wv, ar);
+          ai = fma(c.y, wv, ai);
+        }
       }
     }
     __syncthreads();
+#ifdef SK_STAMPS
+    if (jb == jlo) t3 = __builtin_amdgcn_s_memtime();
+#endif
   }
-  s_red[tid] = make_double2(ar, ai);
+  // fixed-order reduction: sub-lanes of a cell (butterfly), then the NPART waves through LDS
+  for (int off = 1; off < spl; off <<= 1) {
+    ar += __shfl_xor(ar, off, 64);
+    ai += __shfl_xor(ai, off, 64);
+  }
+  if (sub == 0) s_red[part * 64 + cell] = make_double2(ar, ai);
   __syncthreads();
-  if (part == 0) {
-    const int64_t L = L0 + cell;
-    if (cell < ncell) {
+#ifdef SK_STAMPS
+  t4 = __builtin_amdgcn_s_memtime();
+  if (tid == 0 && db.stamps) {
+    unsigned long long* o = db.stamps + (size_t)blockIdx.x * 8;
+    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = (unsigned long long)(jhi - jlo); o[6] = ncell;
+    o[7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID... best effort
+  }
+#endif
+  if (part == 0 && sub == 0 && cell < ncell) {
 #pragma unroll
-      for (int pidx = 1; pidx < NPART; ++pidx) {
-        ar += s_red[pidx * kTileCells + cell].x;
-        ai += s_red[pidx * kTileCells + cell].y;
-      }
-      const int64_t l = L - n1 / 2;
-      // (-1)^l centres the FFT output (index k + n2/2), so k_interp never wraps around
-      const double dcv = ((l & 1) ? -1.0 : 1.0) * dc.deconv[l < 0 ? -l : l];
-      db.fft[(int64_t)rule * n2 + (l < 0 ? l + n2 : l)] = make_double2(ar * dcv, ai * dcv);
+    for (int pidx = 1; pidx < NPART; ++pidx) {
+      ar += s_red[pidx * 64 + cell].x;
+      ai += s_red[pidx * 64 + cell].y;
     }
+    const int64_t l = (int64_t)(L0 + cell) - n1 / 2;
+    // (-1)^l centres the FFT output (index k + n2/2), so k_interp never wraps around
+    const double dcv = ((l & 1) ? -1.0 : 1.0) * dc.deconv[l < 0 ? -l : l];
+    db.fft[(int64_t)rule * n2 + (l < 0 ? l + n2 : l)] = make_double2(ar * dcv, ai * dcv);
   }
 }
 
@@ -580,6 +627,9 @@ void launch_advance(const DevConst& dc, const DevBuffers& db, int slot, hipStrea
     default: { constexpr int W = 16; CALL; } break; \
   }
 
+void launch_gen(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st) {
+  hipLaunchKernelGGL(k_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, slot);
+}
 void launch_spread(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, hipStream_t st) {
   // both variants have their own work list; launch for the longer one (extra blocks zero-pad or idle)
   const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
