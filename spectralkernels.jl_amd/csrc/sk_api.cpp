@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -73,11 +74,10 @@ struct sk_config {
   // per-call workspace (grow only)
   void* ws = nullptr;
   size_t ws_bytes = 0;
-  DevState* h_state = nullptr;  // pinned
-  int* d_flags = nullptr;
-  void* blk_buf = nullptr;
-  size_t blk_cap = 0;
-  int* h_flags = nullptr;
+  HostStatus* h_status = nullptr;  // pinned + device-mapped, written by k_advance
+  unsigned int seq = 0;
+  size_t trace_len = 0;
+  bool trace_valid = false;
   long long* h_nuniq = nullptr;
   hipStream_t own_stream = nullptr;
   // last call
@@ -279,44 +279,53 @@ static int run_fft(sk_config* cfg, hipStream_t st) {
   return SK_OK;
 }
 
+// Waits until k_advance has published status block number `seq` (pinned host memory, polled).
+static int wait_status(sk_config* cfg, unsigned int seq, hipStream_t st) {
+  volatile unsigned int* p = &cfg->h_status->seq;
+  unsigned long long spins = 0;
+  while (*p != seq) {
+    if ((++spins & 0x3fff) == 0) {
+      hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) {
+        if (*p == seq) break;
+        return fail(SK_EHIP, "device finished without publishing its status block");
+      }
+      if (q != hipErrorNotReady) return fail(SK_EHIP, std::string("HIP error: ") + hipGetErrorString(q));
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  cfg->stats.n_syncs++;
+  return SK_OK;
+}
+
 // core march on sorted unique lags already on the device (src/adaptive.jl:110-202)
 static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0, double ks0, double* d_ks, double* d_errs,
-                    double* d_scratch4n, hipStream_t st) {
+                    double* d_scratch6n, hipStream_t st, bool check_flags) {
   DevBuffers& db = cfg->db;
   db.xs = d_uxs;
   db.ks = d_ks;
   db.errs = d_errs;
-  db.accK[0] = d_scratch4n;
+  db.accK[0] = d_scratch6n;
   db.accK[1] = db.accK[0] + n;
   db.accE[0] = db.accK[1] + n;
   db.accE[1] = db.accE[0] + n;
   db.P[0] = db.accE[1] + n;
   db.P[1] = db.P[0] + n;
   db.fvals = cfg->d_fvals;
-  {
-    const size_t nblk = (size_t)((n + 255) / 256) + 1;
-    if (nblk > cfg->blk_cap) {
-      if (cfg->blk_buf) HIPCHK(hipFree(cfg->blk_buf));
-      cfg->blk_buf = nullptr;
-      cfg->blk_cap = 0;
-      HIPCHK(hipMalloc(&cfg->blk_buf, nblk * 2 * (sizeof(double) + sizeof(unsigned int) + sizeof(int))));
-      cfg->blk_cap = nblk * 2;
-    }
-    db.blk_max = (double*)cfg->blk_buf;
-    db.blk_hi = (unsigned int*)(db.blk_max + cfg->blk_cap);
-    db.blk_nan = (int*)(db.blk_hi + cfg->blk_cap);
-  }
-  launch_init(cfg->dc, db, n, k0, ks0, st);
   const bool cb = (cfg->dc.sdf_kind == SK_SDF_CALLBACK);
-  int slot = 0;
-  int R = cb ? 1 : 2;
   sk_stats& stt = cfg->stats;
-  DevState* hs = cfg->h_state;
+  const DevState* hs = &cfg->h_status->state;
+  int t = 0;             // step counter: step t evaluates the panel described by state_t
+  int mode = SK_MODE_INIT;
+  int R = cb ? 1 : 2;
   for (;;) {
     if (cb) {
-      HIPCHK(hipMemcpyAsync(hs, &db.state[slot], sizeof(DevState), hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-      stt.n_syncs++;
+      // host closure: needs state_t (panel bounds) before the step can be generated
+      const unsigned int seq = ++cfg->seq;
+      launch_advance(cfg->dc, db, mode, t, n, k0, ks0, seq, st);
+      int rc = wait_status(cfg, seq, st);
+      if (rc) return rc;
+      if (check_flags && (cfg->h_status->flags[0] || cfg->h_status->flags[1])) return SK_OK;
       if (hs->done) break;
       host_nodes(cfg, hs->pp, cfg->h_nodes);
       cfg->h_fvals.resize(cfg->h_nodes.size());
@@ -324,49 +333,51 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       HIPCHK(hipMemcpyAsync(cfg->d_fvals, cfg->h_fvals.data(), sizeof(double) * cfg->h_fvals.size(),
                             hipMemcpyHostToDevice, st));
       double fb = cfg->sdf(hs->b);
-      HIPCHK(hipMemcpyAsync(&db.state[slot].fb, &fb, sizeof(double), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(&db.state[t & 1].fb, &fb, sizeof(double), hipMemcpyHostToDevice, st));
+      launch_tail(cfg->dc, db, t & 1, st);
+      mode = SK_MODE_ASIS;
     }
     for (int r = 0; r < R; ++r) {
-      if (cb) launch_tail(cfg->dc, db, slot, st);
-      { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, slot, st); }
-      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->ec, db, slot, st); }
+      { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, st); }
+      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->ec, db, t & 1, st); }
       {
         EvScope e(cfg, st, SK_K_FFT);
         int rc = run_fft(cfg, st);
         if (rc) return rc;
       }
-      { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->ec, db, slot, n, st); }
-      { EvScope e(cfg, st, SK_K_ADVANCE); launch_advance(cfg->dc, db, slot, st); }
-      slot ^= 1;
+      { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->ec, db, t & 1, n, st); }
+      ++t;
+      mode = SK_MODE_TRANSITION;
       stt.n_steps_launched++;
     }
     if (!cb) {
-      HIPCHK(hipMemcpyAsync(hs, &db.state[slot], sizeof(DevState), hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-      stt.n_syncs++;
+      const unsigned int seq = ++cfg->seq;
+      { EvScope e(cfg, st, SK_K_ADVANCE); launch_advance(cfg->dc, db, mode, t, n, k0, ks0, seq, st); }
+      int rc = wait_status(cfg, seq, st);
+      if (rc) return rc;
+      if (check_flags && (cfg->h_status->flags[0] || cfg->h_status->flags[1])) return SK_OK;
       if (hs->done) break;
+      mode = SK_MODE_ASIS;
       R = R < 16 ? 2 * R : 16;
     }
   }
   HIPCHK(hipGetLastError());
-  // stats + trace
   stt.n_outer = hs->n_outer;
   stt.n_panels = hs->n_panels;
   stt.n_accepted = hs->n_accepted;
   stt.sum_active = hs->sum_active;
   stt.last_b = hs->b;
-  cfg->trace.resize((size_t)hs->trace_len);
-  if (hs->trace_len)
-    HIPCHK(hipMemcpyAsync(cfg->trace.data(), db.trace, sizeof(TraceRec) * hs->trace_len, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  cfg->trace_len = (size_t)hs->trace_len;
+  cfg->trace_valid = false;
   if (cfg->profile) {
+    HIPCHK(hipStreamSynchronize(st));
     std::memset(&cfg->ktimes, 0, sizeof(cfg->ktimes));
     // only the first n_panels steps did work; later (speculative) steps exit early
     int64_t seen[SK_K_COUNT] = {0};
     for (auto& r : cfg->ev_recs) {
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, r.a, r.b);
-      if (seen[r.kid]++ < hs->n_panels) {
+      if (r.kid == SK_K_ADVANCE || seen[r.kid]++ < hs->n_panels) {
         cfg->ktimes.total_ms[r.kid] += ms;
         cfg->ktimes.launches[r.kid] += 1;
       }
@@ -379,13 +390,6 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     cfg->ev_recs.clear();
     cfg->ev_used = 0;
   }
-#ifdef SK_STAMPS
-  if (const char* f = getenv("SK_STAMP_FILE")) {
-    std::vector<unsigned long long> h(8 * 8192);
-    (void)hipMemcpy(h.data(), db.stamps, h.size() * 8, hipMemcpyDeviceToHost);
-    if (FILE* fp = fopen(f, "wb")) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); }
-  }
-#endif
   if (hs->done < 0) return fail(-hs->done, status_message(-hs->done));
   return SK_OK;
 }
@@ -393,27 +397,32 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
 static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t n, double k0, double ks0, double* d_vals,
                                      double* d_errs, hipStream_t st) {
   std::memset(&cfg->stats, 0, sizeof(cfg->stats));
-  cfg->trace.clear();
+  cfg->trace_len = 0;
+  cfg->trace_valid = false;
   if (n == 0) return SK_OK;
   if (n > (size_t)0x7fffffff) return fail(SK_EINVAL, "at most 2^31-1 lags per call");
   HIPCHK(hipSetDevice(cfg->device));
-  HIPCHK(hipMemsetAsync(cfg->d_flags, 0, 2 * sizeof(int), st));
-  launch_check_sorted(d_xs, (long long)n, cfg->d_flags, st);
-  HIPCHK(hipMemcpyAsync(cfg->h_flags, cfg->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  cfg->stats.n_syncs++;
-  if (cfg->h_flags[1]) return fail(SK_EINVAL, "lags must be non-negative and finite");
   const size_t a8 = ((n * 8 + 255) / 256) * 256;
-  if (!cfg->h_flags[0]) {
-    // strictly increasing: outputs double as accumulators
-    int rc = ensure_ws(cfg, 6 * a8);
-    if (rc) return rc;
-    cfg->stats.n_unique = (int64_t)n;
-    return run_core(cfg, d_xs, (long long)n, k0, ks0, d_vals, d_errs, (double*)cfg->ws, st);
+  int rc = ensure_ws(cfg, 6 * a8);
+  if (rc) return rc;
+  // The input is checked for "strictly increasing, >= 0" on the device and the march starts
+  // speculatively on it as is; the flags come back with the first status block (no extra sync).
+  launch_check_sorted(d_xs, (long long)n, cfg->db.flags, st);
+  cfg->stats.n_unique = (int64_t)n;
+  rc = run_core(cfg, d_xs, (long long)n, k0, ks0, d_vals, d_errs, (double*)cfg->ws, st, true);
+  const int unsorted = cfg->h_status->flags[0], invalid = cfg->h_status->flags[1];
+  if (unsorted || invalid) {
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemsetAsync(cfg->db.flags, 0, 2 * sizeof(int), st));
+    cfg->ev_recs.clear();
+    cfg->ev_used = 0;
   }
+  if (invalid) return fail(SK_EINVAL, "lags must be non-negative and finite");
+  if (!unsorted) return rc;
   // src/adaptive.jl:99-120: unique + sort, then gather back
+  std::memset(&cfg->stats, 0, sizeof(cfg->stats));
   const size_t tb = sort_unique_temp_bytes((long long)n);
-  int rc = ensure_ws(cfg, 10 * a8 + tb + 256);
+  rc = ensure_ws(cfg, 10 * a8 + tb + 256);
   if (rc) return rc;
   char* base = (char*)cfg->ws;
   double* uxs = (double*)base; base += a8;
@@ -428,7 +437,7 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   cfg->stats.n_syncs++;
   const long long nu = *cfg->h_nuniq;
   cfg->stats.n_unique = nu;
-  rc = run_core(cfg, uxs, nu, k0, ks0, ks, errs, scr, st);
+  rc = run_core(cfg, uxs, nu, k0, ks0, ks, errs, scr, st, false);
   if (rc) return rc;
   launch_gather(ks, errs, inv, (long long)n, d_vals, d_errs, st);
   HIPCHK(hipStreamSynchronize(st));
@@ -576,17 +585,19 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   DA(2, db.state); DA(kStackCap, db.stack); DA(kTraceCap, db.trace);
   DA((size_t)3 * cfg->M, db.src); DA((size_t)2 * dc.n2, db.fft);
   DA((size_t)3 * cfg->M, cfg->d_fvals);
-  DA(2, cfg->d_flags);
+  DA(2, db.flags); DA(2, db.red);
+  (void)hipMemset(db.flags, 0, 2 * sizeof(int));
 #ifdef SK_STAMPS
   DA(8 * 8192, db.stamps);
 #endif
 #undef DA
-  if (hipHostMalloc((void**)&cfg->h_state, sizeof(DevState)) != hipSuccess ||
-      hipHostMalloc((void**)&cfg->h_flags, 2 * sizeof(int)) != hipSuccess ||
+  if (hipHostMalloc((void**)&cfg->h_status, sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&db.host_status, cfg->h_status, 0) != hipSuccess ||
       hipHostMalloc((void**)&cfg->h_nuniq, sizeof(long long)) != hipSuccess) {
     sk_config_destroy(cfg);
     return fail(SK_EHIP, "hipHostMalloc failed");
   }
+  std::memset(cfg->h_status, 0, sizeof(HostStatus));
   if (hipStreamCreate(&cfg->own_stream) != hipSuccess) {
     sk_config_destroy(cfg);
     return fail(SK_EHIP, "hipStreamCreate failed");
@@ -628,9 +639,7 @@ void sk_config_destroy(sk_config* cfg) {
   if (cfg->fft_work) hipFree(cfg->fft_work);
   for (void* p : cfg->owned) hipFree(p);
   if (cfg->ws) hipFree(cfg->ws);
-  if (cfg->blk_buf) hipFree(cfg->blk_buf);
-  if (cfg->h_state) hipHostFree(cfg->h_state);
-  if (cfg->h_flags) hipHostFree(cfg->h_flags);
+  if (cfg->h_status) hipHostFree(cfg->h_status);
   if (cfg->h_nuniq) hipHostFree(cfg->h_nuniq);
   if (cfg->own_stream) hipStreamDestroy(cfg->own_stream);
   for (hipEvent_t e : cfg->ev_pool) hipEventDestroy(e);
@@ -776,8 +785,17 @@ int sk_last_stats(const sk_config* cfg, sk_stats* out) {
   return SK_OK;
 }
 
-int sk_last_trace(const sk_config* cfg, double* rec, size_t cap, size_t* len) {
-  if (!cfg || !len) return fail(SK_EINVAL, "null argument");
+int sk_last_trace(const sk_config* cfg_c, double* rec, size_t cap, size_t* len) {
+  if (!cfg_c || !len) return fail(SK_EINVAL, "null argument");
+  sk_config* cfg = const_cast<sk_config*>(cfg_c);
+  if (!cfg->trace_valid) {  // fetched lazily: the records stay in device memory until the next call
+    cfg->trace.resize(cfg->trace_len);
+    if (cfg->trace_len) {
+      HIPCHK(hipSetDevice(cfg->device));
+      HIPCHK(hipMemcpy(cfg->trace.data(), cfg->db.trace, sizeof(TraceRec) * cfg->trace_len, hipMemcpyDeviceToHost));
+    }
+    cfg->trace_valid = true;
+  }
   size_t nrec = cfg->trace.size() < cap ? cfg->trace.size() : cap;
   for (size_t i = 0; i < nrec; ++i) {
     const TraceRec& r = cfg->trace[i];

@@ -81,7 +81,25 @@ struct DevState {
   int trace_len;
 };
 
+// how k_gen / k_advance obtain the state of their step (see step_state in sk_kernels.hip)
+enum { SK_MODE_INIT = 0, SK_MODE_TRANSITION = 1, SK_MODE_ASIS = 2 };
+
 struct TraceRec { double a, b, max_err, n_active, accepted; };
+
+// Reductions of one k_interp launch, spread over 64 addresses to keep the atomics uncontended.
+struct Reductions {
+  unsigned long long max_bits[64];  // max |I2-I1| (bit pattern of a non-negative double)
+  unsigned int hi[64];              // highest lag failing the convergence predicate, +1
+  int nan;                          // bit 0: NaN in I1, bit 1: NaN in I2
+  int pad[15];
+};
+
+// Pinned, host-mapped block through which k_advance reports the state (polled by the host).
+struct HostStatus {
+  DevState state;
+  int flags[2];       // k_check_sorted: [0] not strictly increasing, [1] negative or NaN lag
+  unsigned int seq;
+};
 
 struct DevBuffers {
   DevState* state;          // 2 slots (ping-pong)
@@ -96,17 +114,20 @@ struct DevBuffers {
   double* P[2];             // ping-pong outer-panel partial sums (bisection only)
   // per-workgroup partial reductions of k_interp (no same-address atomics): max |I2-I1| bits,
   // highest unconverged lag + 1, NaN flags (bit 0: I1, bit 1: I2)
-  double* blk_max; unsigned int* blk_hi; int* blk_nan;
+  Reductions* red;          // 2 slots (step parity)
+  HostStatus* host_status;  // device view of the pinned status block
+  int* flags;               // k_check_sorted flags (reset by k_advance once reported)
   unsigned long long* stamps;  // diagnostic builds only (SK_STAMPS): 8 words per k_spread workgroup
 };
 
 // launchers (sk_kernels.hip)
-void launch_init(const DevConst& dc, const DevBuffers& db, long long n, double k0, double ks0, hipStream_t st);
 void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);  // callback SDFs only
-void launch_gen(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);
+void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
+                hipStream_t st);
 void launch_spread(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, hipStream_t st);
 void launch_interp(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, long long n, hipStream_t st);
-void launch_advance(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);
+void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
+                    unsigned int seq, hipStream_t st);
 
 // seam kernels for sk_panel_sums
 void launch_seam_spread(const DevConst& dc, const double* nodes, const double* coef, int64_t M, double Cx, double X,

@@ -8,8 +8,10 @@
 //             163-164, :194), interpolates at the active lags, post-phase, scaling, |I2-I1| and its
 //             max (src/quadrature.jl:130-136, :250-258) and the speculative convergence predicate
 //             (src/adaptive.jl:183-198, :222-233)
-//   k_advance scalar transition: accept/reject (src/quadrature.jl:260), bisection stack (:268-270),
-//             next outer panel (src/adaptive.jl:149-152), tail fit (src/adaptive.jl:204-220)
+// The scalar transition between steps -- accept/reject (src/quadrature.jl:260), bisection stack
+// (:268-270), next outer panel (src/adaptive.jl:149-152), tail fit (src/adaptive.jl:204-220) -- is
+// evaluated redundantly by every workgroup of the next k_gen (no extra launch); k_advance runs it
+// only at round boundaries, where the host reads the state through a pinned status block.
 // All state lives in HBM (DevState ping-pong), so steps run back to back with no host hop.
 #include <cstring>
 #include <cmath>
@@ -121,8 +123,8 @@ __device__ __forceinline__ bool step_accept(const DevState& s, double tol) {
   return !s.nan1 && (maxe < tol * s.k0abs);  // src/quadrature.jl:260
 }
 
-__global__ void k_init(DevConst dc, DevBuffers db, long long n, double k0, double ks0) {
-  DevState s;
+// Initial state (src/adaptive.jl:122-146): everything active, first outer panel.
+__device__ void init_state(DevState& s, const DevConst& dc, const DevBuffers& db, long long n, double k0, double ks0) {
   memset(&s, 0, sizeof(s));
   s.n = n;
   s.k0abs = fabs(k0);
@@ -130,16 +132,123 @@ __global__ void k_init(DevConst dc, DevBuffers db, long long n, double k0, doubl
   s.hi = n;
   s.ix1 = (n > 0 && db.xs[0] == 0.0) ? 1 : 0;  // src/adaptive.jl:132-133
   s.crit = dc.crit0;
-  s.a = 0.0;
-  s.b = 0.0;
   s.hi_new = (unsigned long long)s.ix1;
-  if (s.ix1 == 1) {  // src/adaptive.jl:132-146
-    db.ks[0] = ks0;
-    db.errs[0] = __builtin_nan("");
-  }
   setup_outer(s, dc, db.xs);
-  db.state[0] = s;
-  db.state[1] = s;
+}
+
+// Scalar transition after one (sub)panel evaluation: accept/reject (src/quadrature.jl:260),
+// bisection stack (:268-270), next outer panel (src/adaptive.jl:149-152, :168-199).  Pure function of
+// (state, reductions) except for the stack push and the trace record, which only the caller with
+// side_effects == true performs (every workgroup of k_gen evaluates it redundantly in registers).
+__device__ void transition(DevState& s, const DevConst& dc, const DevBuffers& db, double red_max, unsigned int red_hi,
+                           int red_nan, bool side_effects) {
+  if (s.done) return;
+  s.nan1 = red_nan & 1;
+  s.nan2 = (red_nan >> 1) & 1;
+  // a NaN in int1 makes maximum(_err) NaN in the reference, which is never < tol*k0
+  s.max_err_bits = (unsigned long long)__double_as_longlong(s.nan1 ? __builtin_nan("") : red_max);
+  s.hi_new = red_hi > (unsigned long long)s.ix1 ? (unsigned long long)red_hi : (unsigned long long)s.ix1;
+  const bool accept = step_accept(s, dc.tol);
+  const long long nact = s.hi - s.ix1;
+  if (s.trace_len < kTraceCap) {
+    if (side_effects) {
+      TraceRec r;
+      r.a = s.pp.pa;
+      r.b = s.pp.pb;
+      r.max_err = __longlong_as_double((long long)s.max_err_bits);
+      r.n_active = (double)nact;
+      r.accepted = accept ? 1.0 : 0.0;
+      db.trace[s.trace_len] = r;
+    }
+    s.trace_len++;
+  }
+  s.n_panels += 1;
+  s.sum_active += nact;
+  s.hi_prev = s.hi;
+  if (!s.nan1 && s.nan2) {  // src/quadrature.jl:165 (throws only when int1 is NaN-free)
+    s.done = -SK_ENAN;
+  } else if (accept) {
+    s.n_accepted += 1;
+    s.conf ^= 1;  // the optimistic sums of this evaluation become the confirmed ones
+    s.has_acc = 1;
+    if (s.stack_len > 0) {
+      s.pc ^= 1;  // k_interp stored P + I2 in the other P buffer
+      s.p_valid = 1;
+      double2 ab = db.stack[--s.stack_len];
+      set_panel(s, dc, db.xs, ab.x, ab.y);
+    } else {
+      // outer panel complete: src/adaptive.jl:168-199
+      s.p_valid = 0;
+      s.crit = s.tail.crit;  // a NaN tail fit switches to :panel for the rest of the call
+      s.hi = (long long)s.hi_new;
+      setup_outer(s, dc, db.xs);
+    }
+  } else {
+    // src/quadrature.jl:268-270: push left, then right; right is popped next.
+    if (s.stack_len + 2 > kStackCap) {
+      s.done = -SK_ESTACK;
+    } else {
+      double mid = 0.5 * (s.pp.pa + s.pp.pb);
+      if (side_effects) db.stack[s.stack_len] = make_double2(s.pp.pa, mid);
+      s.stack_len++;
+      set_panel(s, dc, db.xs, mid, s.pp.pb);
+    }
+  }
+  s.max_err_bits = 0ull;
+  s.hi_new = (unsigned long long)s.ix1;
+  s.nan1 = 0;
+  s.nan2 = 0;
+}
+
+
+// Workgroup prologue shared by k_gen and k_advance: produces the state of step `t` in LDS.
+//   INIT        state_0 from the lags;
+//   TRANSITION  state_t = T(state_{t-1}, reductions of k_interp(t-1));
+//   ASIS        state_t was already written by k_advance.
+// The workgroup with blockIdx 0 publishes it to db.state[t & 1] and performs the side effects.
+__device__ void step_state(DevState& sh, const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0,
+                           double ks0) {
+  __shared__ double r_max;
+  __shared__ unsigned int r_hi;
+  __shared__ int r_nan;
+  const bool lead = (blockIdx.x == 0);
+  if (mode == SK_MODE_TRANSITION && threadIdx.x < 64) {
+    const Reductions& rd = db.red[(t - 1) & 1];
+    double m = __longlong_as_double((long long)rd.max_bits[threadIdx.x]);
+    unsigned int h = rd.hi[threadIdx.x];
+    for (int off = 32; off > 0; off >>= 1) {
+      m = fmax(m, __shfl_xor(m, off, 64));
+      const unsigned int o = __shfl_xor(h, off, 64);
+      h = o > h ? o : h;
+    }
+    if (threadIdx.x == 0) {
+      r_max = m;
+      r_hi = h;
+      r_nan = rd.nan;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (mode == SK_MODE_INIT) {
+      init_state(sh, dc, db, n, k0, ks0);
+      if (lead && sh.ix1 == 1) {  // src/adaptive.jl:132-146
+        db.ks[0] = ks0;
+        db.errs[0] = __builtin_nan("");
+      }
+    } else {
+      sh = db.state[(mode == SK_MODE_TRANSITION ? t - 1 : t) & 1];
+      if (mode == SK_MODE_TRANSITION) transition(sh, dc, db, r_max, r_hi, r_nan, lead);
+    }
+    if (lead && mode != SK_MODE_ASIS) db.state[t & 1] = sh;
+  }
+  // reset the reduction slots that k_interp(t) will accumulate into (last read by k_gen(t-1))
+  if (lead && threadIdx.x < 64) {
+    Reductions& rn = db.red[t & 1];
+    rn.max_bits[threadIdx.x] = 0ull;
+    rn.hi[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) rn.nan = 0;
+  }
+  __syncthreads();
 }
 
 // Callback SDFs: the host uploads S(b) into state.fb before the step, then this computes the tail.
@@ -149,92 +258,20 @@ __global__ void k_tail(DevConst dc, DevBuffers db, int slot) {
   tail_scalars(s, dc);
 }
 
-__global__ void __launch_bounds__(256) k_advance(DevConst dc, DevBuffers db, int slot) {
-  __shared__ double smax[256];
-  __shared__ unsigned int shi[256];
-  __shared__ int snan[256];
-  {
-    // reduce the per-workgroup partials that k_interp wrote for the active range [0, hi)
-    const DevState& s0 = db.state[slot];
-    const long long nb = s0.done ? 0 : (s0.hi + 255) / 256;
-    double m = 0.0;
-    unsigned int h = 0u;
-    int f = 0;
-    for (long long b = threadIdx.x; b < nb; b += blockDim.x) {
-      m = fmax(m, db.blk_max[b]);
-      const unsigned int hb = db.blk_hi[b];
-      h = hb > h ? hb : h;
-      f |= db.blk_nan[b];
-    }
-    smax[threadIdx.x] = m;
-    shi[threadIdx.x] = h;
-    snan[threadIdx.x] = f;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off) {
-        smax[threadIdx.x] = fmax(smax[threadIdx.x + off], smax[threadIdx.x]);
-        shi[threadIdx.x] = shi[threadIdx.x + off] > shi[threadIdx.x] ? shi[threadIdx.x + off] : shi[threadIdx.x];
-        snan[threadIdx.x] |= snan[threadIdx.x + off];
-      }
-      __syncthreads();
-    }
+// Round boundary: materialises state_t for the host (pinned, host-mapped status block) without
+// launching the next step.
+__global__ void __launch_bounds__(64) k_advance(DevConst dc, DevBuffers db, int mode, int t, long long n, double k0,
+                                                 double ks0, unsigned int seq) {
+  __shared__ DevState sh;
+  step_state(sh, dc, db, mode, t, n, k0, ks0);
+  if (threadIdx.x == 0) {
+    HostStatus* hs = db.host_status;
+    hs->state = sh;
+    hs->flags[0] = db.flags[0];
+    hs->flags[1] = db.flags[1];
+    __threadfence_system();
+    __hip_atomic_store(&hs->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (threadIdx.x != 0) return;
-  DevState s = db.state[slot];
-  s.nan1 = snan[0] & 1;
-  s.nan2 = (snan[0] >> 1) & 1;
-  // a NaN in int1 makes maximum(_err) NaN in the reference, which is never < tol*k0
-  s.max_err_bits = (unsigned long long)__double_as_longlong(s.nan1 ? __builtin_nan("") : smax[0]);
-  s.hi_new = shi[0] > (unsigned long long)s.ix1 ? (unsigned long long)shi[0] : (unsigned long long)s.ix1;
-  if (!s.done) {
-    const bool accept = step_accept(s, dc.tol);
-    const long long nact = s.hi - s.ix1;
-    if (s.trace_len < kTraceCap) {
-      TraceRec r;
-      r.a = s.pp.pa;
-      r.b = s.pp.pb;
-      r.max_err = __longlong_as_double((long long)s.max_err_bits);
-      r.n_active = (double)nact;
-      r.accepted = accept ? 1.0 : 0.0;
-      db.trace[s.trace_len++] = r;
-    }
-    s.n_panels += 1;
-    s.sum_active += nact;
-    s.hi_prev = s.hi;
-    if (!s.nan1 && s.nan2) {  // src/quadrature.jl:165 (throws only when int1 is NaN-free)
-      s.done = -SK_ENAN;
-    } else if (accept) {
-      s.n_accepted += 1;
-      s.conf ^= 1;  // the optimistic sums of this evaluation become the confirmed ones
-      s.has_acc = 1;
-      if (s.stack_len > 0) {
-        s.pc ^= 1;  // k_interp stored P + I2 in the other P buffer
-        s.p_valid = 1;
-        double2 ab = db.stack[--s.stack_len];
-        set_panel(s, dc, db.xs, ab.x, ab.y);
-      } else {
-        // outer panel complete: src/adaptive.jl:168-199
-        s.p_valid = 0;
-        s.crit = s.tail.crit;  // a NaN tail fit switches to :panel for the rest of the call
-        s.hi = (long long)s.hi_new;
-        setup_outer(s, dc, db.xs);
-      }
-    } else {
-      // src/quadrature.jl:268-270: push left, then right; right is popped next.
-      if (s.stack_len + 2 > kStackCap) {
-        s.done = -SK_ESTACK;
-      } else {
-        double mid = 0.5 * (s.pp.pa + s.pp.pb);
-        db.stack[s.stack_len++] = make_double2(s.pp.pa, mid);
-        set_panel(s, dc, db.xs, mid, s.pp.pb);
-      }
-    }
-    s.max_err_bits = 0ull;
-    s.hi_new = (unsigned long long)s.ix1;
-    s.nan1 = 0;
-    s.nan2 = 0;
-  }
-  db.state[slot ^ 1] = s;
 }
 
 // ------------------------------------------------------------------ ES kernel evaluation
@@ -275,10 +312,12 @@ constexpr int kSpreadThreads = 256;
 // k_gen: one thread per quadrature node of the current (sub)panel, both rules: node, SDF value,
 // Gauss weight (updatequadbufs!, src/quadrature.jl:49-95) and the type-3 pre-phase; writes the
 // complex source strengths c'_j (rule 1: M entries, then rule 2: 2M entries).
-__global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int slot) {
-  const DevState& s = db.state[slot];
-  if (s.done) return;
-  const PanelParams pp = s.pp;
+__global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mode, int t, long long n, double k0,
+                                             double ks0) {
+  __shared__ DevState sh;
+  step_state(sh, dc, db, mode, t, n, k0, ks0);
+  if (sh.done) return;
+  const PanelParams pp = sh.pp;
   const int64_t M = dc.M;
   const int64_t jg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (jg >= 3 * M) return;
@@ -470,7 +509,10 @@ __device__ __forceinline__ void interp_core(const DevConst& dc, const double* s_
   const double y = (k0d - tcn) - 0.5;
   const double y2 = y * y;
   // the FFT output is centred (see k_spread): tap q sits at index k0 + q + n2/2, no wrap-around
-  const double2* __restrict__ f1 = fft + ((int)k0d + n2 / 2);
+  // clamped: valid inputs (0 <= r <= r_hi) never need it, but the march may start speculatively on
+  // unsorted or invalid lags (see kernel_values_device_impl) and must not read out of bounds then
+  int base = (int)fmin(fmax(k0d, -(double)(n2 / 2)), (double)(n2 / 2 - W)) + n2 / 2;
+  const double2* __restrict__ f1 = fft + base;
   // kernel weights first (24 VGPRs), then the taps: the compiler batches the independent gathers
   double wt[W];
 #pragma unroll
@@ -596,9 +638,13 @@ __global__ void __launch_bounds__(256, 4) k_interp(DevConst dc, EsConst ec, DevB
       b = fmax(b, smax[w2]);
       h = shi[w2] > h ? shi[w2] : h;
     }
-    db.blk_max[blockIdx.x] = b;
-    db.blk_hi[blockIdx.x] = h;
-    db.blk_nan[blockIdx.x] = sflag[0] | (sflag[1] << 1);
+    // 64-way spread atomics (about 60 arrivals per address for 10^6 lags), reduced by the next k_gen
+    Reductions& rd = db.red[slot];
+    const int a = blockIdx.x & 63;
+    if (b > 0.0) atomicMax(&rd.max_bits[a], (unsigned long long)__double_as_longlong(b));
+    if (h) atomicMax(&rd.hi[a], h);
+    const int f = sflag[0] | (sflag[1] << 1);
+    if (f) atomicOr(&rd.nan, f);
   }
 }
 
@@ -606,14 +652,13 @@ __global__ void __launch_bounds__(256, 4) k_interp(DevConst dc, EsConst ec, DevB
 
 static inline unsigned nblk(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
-void launch_init(const DevConst& dc, const DevBuffers& db, long long n, double k0, double ks0, hipStream_t st) {
-  hipLaunchKernelGGL(k_init, dim3(1), dim3(1), 0, st, dc, db, n, k0, ks0);
-}
+
 void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st) {
   hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, st, dc, db, slot);
 }
-void launch_advance(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st) {
-  hipLaunchKernelGGL(k_advance, dim3(1), dim3(256), 0, st, dc, db, slot);
+void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
+                    unsigned int seq, hipStream_t st) {
+  hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, dc, db, mode, t, n, k0, ks0, seq);
 }
 
 #define SK_DISPATCH_W(w, CALL) \
@@ -627,8 +672,9 @@ void launch_advance(const DevConst& dc, const DevBuffers& db, int slot, hipStrea
     default: { constexpr int W = 16; CALL; } break; \
   }
 
-void launch_gen(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st) {
-  hipLaunchKernelGGL(k_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, slot);
+void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
+                hipStream_t st) {
+  hipLaunchKernelGGL(k_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, mode, t, n, k0, ks0);
 }
 void launch_spread(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, hipStream_t st) {
   // both variants have their own work list; launch for the longer one (extra blocks zero-pad or idle)
