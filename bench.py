@@ -132,16 +132,18 @@ def main():
     dom = max(acc, key=lambda k: acc[k]["total_ms"])
     # algorithmic bytes per launch: interp/accum per active lag, gen/spread per panel
     M = cfg.quadspec[0] * cfg.quadspec[1]
-    # interp: read r (8) + write I2 and |I2-I1| (16) + read-modify-write of the K and err accumulators (32)
-    alg_bytes = {"interp": 56.0}
+    # interp per active lag: read r (8) + confirmed sums (16, not on the very first panel) and write the
+    # optimistic sums (16) and the outputs (16)  -> 56 B, 40 B on the first panel (Kernels)
+    n_first = st["n_unique"] - (1 if rs[0] == 0.0 else 0)
+    interp_bytes_total = 10 * (56.0 * st["sum_active"] - 16.0 * n_first)  # over the 10 profiled calls
     rl = {}
     for k, v in acc.items():
         if v["launches"] == 0:
             continue
         avg_ms = v["total_ms"] / v["launches"]
         items = v["active_items"] / v["launches"]
-        if k in alg_bytes:
-            b = alg_bytes[k] * items
+        if k == "interp":
+            b = interp_bytes_total / v["launches"]
         elif k == "gen":
             b = 48.0 * M + 48.0 * M  # read node + weight of both rules (M + 2M) x (8 + 8), write 3M complex strengths
         elif k == "spread":
@@ -153,8 +155,19 @@ def main():
         rl[k] = dict(avg_us=1e3 * avg_ms, bytes=b, gbps=(b / (avg_ms * 1e-3) / 1e9) if avg_ms > 0 else 0.0,
                      launches_per_step=v["launches"] / 10.0)
     peak = 8000.0
+    # HBM bytes per launch of the dominant kernel from the committed PMC summary of this round
+    # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/profile_round.sh)
+    traffic = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_%s_summary.json" % args.workload.lower())))
+        for kname, tv in pj.get("traffic", {}).items():
+            if ("k_" + dom) in kname:
+                traffic = tv["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": rl[dom]["gbps"], "peak": peak, "unit": "GB/s",
-                "frac": rl[dom]["gbps"] / peak, "traffic": None, "avg_us": rl[dom]["avg_us"],
+                "frac": rl[dom]["gbps"] / peak, "traffic": traffic, "avg_us": rl[dom]["avg_us"],
+                "algorithmic_bytes_per_launch": rl[dom]["bytes"],
                 "per_kernel": {k: {"avg_us": round(v["avg_us"], 3), "GB/s": round(v["gbps"], 1),
                                    "launches_per_step": v["launches_per_step"]} for k, v in rl.items()}}
     # whole-step view: algorithmic bytes per lag (24 + 40*abar + 48*M*Q/N) over the step time
@@ -164,21 +177,33 @@ def main():
     roofline["step_frac"] = roofline["step_GB/s"] / peak
     roofline["bytes_per_lag"] = bytes_per_lag
 
-    # ---- CPU baseline: the oracle (a port, not FINUFFT) on a bounded sample of the same workload
+    # ---- CPU baseline: the oracle (a port of the reference's algorithm, not FINUFFT) on the GPU box's
+    # host cores: the whole workload with the oracle's CPU type-3 NUFFT, plus a small exact-direct-sum sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import sk_oracle as o
+        ocfg = o.AdaptiveKernelConfig(getattr(o.SDF, kind)(*prm), use_nufft=True, **w["kw"])
+        o.gauss_rules(ocfg.quadspec[0], ocfg.p)
+        best, reps, oks = None, 0, None
+        t_all = time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t_all < 10.0 and reps < 20):
+            tc = time.perf_counter()
+            oks, _ = o.kernel_values(ocfg, rs, k0=k0)
+            dtc = time.perf_counter() - tc
+            best = dtc if best is None else min(best, dtc)
+            reps += 1
         ns = args.cpu_sample or (2000 if M > 10000 else 20000)
         idx = np.unique(np.r_[np.linspace(0, n - 1, ns).astype(int), n - 1])
-        ocfg = o.AdaptiveKernelConfig(getattr(o.SDF, kind)(*prm), **w["kw"])
-        o.gauss_rules(ocfg.quadspec[0], ocfg.p)
+        dcfg = o.AdaptiveKernelConfig(getattr(o.SDF, kind)(*prm), **w["kw"])
         tc = time.perf_counter()
-        oks, _ = o.kernel_values(ocfg, rs[idx], k0=k0)
-        tcpu = time.perf_counter() - tc
-        cpu = {"value": idx.size / tcpu, "unit": "r-targets/s", "cores": ocfg.nthreads, "kind": "port",
-               "sample": "%d of the %d lags (every ~%d-th, incl. the largest), exact direct sums in the oracle "
-                         "(no NUFFT); %.1f s" % (idx.size, n, n // idx.size, tcpu),
-               "max_abs_diff_vs_gpu_over_k0": float(np.abs(oks - ks[idx]).max() / abs(k0))}
+        dks, _ = o.kernel_values(dcfg, rs[idx], k0=k0)
+        tdir = time.perf_counter() - tc
+        cpu = {"value": n / best, "unit": "r-targets/s", "cores": ocfg.nthreads, "kind": "port",
+               "sample": "all %d lags, oracle with its CPU type-3 NUFFT (OpenMP), best of %d runs, %.2f s each; "
+                         "exact direct sums on %d of the lags: %.0f r-targets/s" % (n, reps, best, idx.size,
+                                                                                     idx.size / tdir),
+               "max_abs_diff_vs_gpu_over_k0": float(np.abs(oks - ks).max() / abs(k0)),
+               "direct_sum_sample_diff_vs_gpu_over_k0": float(np.abs(dks - ks[idx]).max() / abs(k0))}
 
     if rank == 0:
         out = {"metric": "r-targets/sec at tol=1e-8", "value": value, "unit": "r-targets/s", "n_gpus": world,

@@ -34,7 +34,7 @@ class _Cfg(C.Structure):
                 ("m", C.c_long), ("k", C.c_long),
                 ("leg_no1", C.c_void_p), ("leg_wt1", C.c_void_p), ("leg_no2", C.c_void_p), ("leg_wt2", C.c_void_p),
                 ("jac_no1", C.c_void_p), ("jac_wt1", C.c_void_p), ("jac_no2", C.c_void_p), ("jac_wt2", C.c_void_p),
-                ("nthreads", C.c_int)]
+                ("nthreads", C.c_int), ("use_nufft", C.c_int)]
 
 
 class _Rec(C.Structure):
@@ -115,7 +115,8 @@ class AdaptiveKernelConfig:
     """src/adaptive.jl:2-59 (struct + constructor), same keyword names."""
 
     def __init__(self, f, df=None, dim=1, alpha=0.0, tol=1e-8, derivative=False, logw=False,
-                 convergence_criteria="both", tail=None, quadspec=(2 ** 12, 2 ** 4), nthreads=None):
+                 convergence_criteria="both", tail=None, quadspec=(2 ** 12, 2 ** 4), nthreads=None,
+                 use_nufft=False):
         if not isinstance(f, SDF):
             f = SDF.callback(f)
         if convergence_criteria not in CRITERIA:
@@ -140,6 +141,7 @@ class AdaptiveKernelConfig:
         else:
             self.jac = self.leg
         self.nthreads = nthreads if nthreads else lib().sko_max_threads()
+        self.use_nufft = bool(use_nufft)  # CPU type-3 NUFFT for the panel sums (baseline timing only)
         self._keep = None
 
     def _cstruct(self):
@@ -160,6 +162,7 @@ class AdaptiveKernelConfig:
         (s.leg_no1, s.leg_wt1, s.leg_no2, s.leg_wt2) = [_ptr(a) for a in self.leg]
         (s.jac_no1, s.jac_wt1, s.jac_no2, s.jac_wt2) = [_ptr(a) for a in self.jac]
         s.nthreads = self.nthreads
+        s.use_nufft = int(self.use_nufft)
         return s
 
 
