@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libspectralkernels_hip.so")
+LIB_PATH = os.environ.get("SPECTRALKERNELS_HIP_LIB", os.path.join(HERE, "libspectralkernels_hip.so"))
 
 SK_OK, SK_EINVAL, SK_ESUBDIVIDE, SK_ENAN, SK_ESTACK, SK_EHIP, SK_ENODEVICE, SK_EUNSUPPORTED = range(8)
 SK_WARN_QUADSPEC = 100

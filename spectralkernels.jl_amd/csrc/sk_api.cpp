@@ -65,6 +65,7 @@ struct sk_config {
   // device
   DevConst dc;
   EsConst ec;
+  EsConst* d_ec = nullptr;
   DevBuffers db;
   std::vector<void*> owned;  // device allocations freed at destroy
   rocfft_plan plan = nullptr;
@@ -339,13 +340,13 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     }
     for (int r = 0; r < R; ++r) {
       { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, st); }
-      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->ec, db, t & 1, st); }
+      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->d_ec, db, t & 1, st); }
       {
         EvScope e(cfg, st, SK_K_FFT);
         int rc = run_fft(cfg, st);
         if (rc) return rc;
       }
-      { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->ec, db, t & 1, n, st); }
+      { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->d_ec, db, t & 1, n, st); }
       ++t;
       mode = SK_MODE_TRANSITION;
       stt.n_steps_launched++;
@@ -390,6 +391,13 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     cfg->ev_recs.clear();
     cfg->ev_used = 0;
   }
+#ifdef SK_STAMPS
+  if (const char* f = getenv("SK_STAMP_FILE")) {
+    std::vector<unsigned long long> h(8 * 8192);
+    (void)hipMemcpy(h.data(), db.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen(f, "wb")) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); }
+  }
+#endif
   if (hs->done < 0) return fail(-hs->done, status_message(-hs->done));
   return SK_OK;
 }
@@ -552,6 +560,12 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   std::memset(&cfg->ec, 0, sizeof(cfg->ec));
   std::memcpy(cfg->ec.poly, cfg->tab.poly.data(), cfg->tab.poly.size() * sizeof(double));
   std::memcpy(cfg->ec.cheb, cfg->tab.cheb.data(), cfg->tab.cheb.size() * sizeof(double));
+  {
+    std::vector<EsConst> v(1, cfg->ec);
+    const EsConst* dptr = nullptr;
+    UP(v, dptr);
+    cfg->d_ec = const_cast<EsConst*>(dptr);
+  }
   for (int variant = 0; variant < 2; ++variant) {
     if (variant == 1 && cfg->p == 0.0) {
       for (int rule = 0; rule < 2; ++rule) {
@@ -757,7 +771,7 @@ int sk_panel_sums(sk_config* cfg, const double* nodes, const double* coef, size_
     launch_seam_deconv(dc, cfg->db.fft, st);
     rc = run_fft(cfg, st);
     if (rc) return done(rc);
-    launch_seam_interp(dc, cfg->ec, cfg->db.fft, d_xs, (int64_t)n, Cx, r_hi, tau, theta_scale, d_re, d_im, st);
+    launch_seam_interp(dc, cfg->d_ec, cfg->db.fft, d_xs, (int64_t)n, Cx, r_hi, tau, theta_scale, d_re, d_im, st);
   }
   if (hipMemcpyAsync(out_re, d_re, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipMemcpyAsync(out_im, d_im, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -6,7 +6,7 @@
 namespace sk {
 
 constexpr int kMaxWidth = 16;
-constexpr int kMaxNco = kMaxWidth / 2 + 2;
+constexpr int kMaxNco = kMaxWidth / 2 + 1;
 constexpr int kMaxCheb = 24;
 constexpr int kStackCap = 5000;  // src/quadrature.jl:7
 constexpr int kTraceCap = 4096;
@@ -35,17 +35,18 @@ struct DevConst {
   int ntiles[2];
 };
 
-// ES-kernel tables passed BY VALUE (kernarg segment => scalar loads, no LDS, no vector loads):
+// ES-kernel tables (device memory; every workgroup stages them in LDS):
 // piecewise-polynomial coefficients and the Chebyshev series of 1/phi_hat.
 struct EsConst {
   double poly[(kMaxWidth / 2) * 2 * kMaxNco];
-  double cheb[20];
+  double cheb[16];
 };
 
 struct PanelParams {
   double pa, pb;        // current (sub)panel
   double Cx, X;         // centre, half-width
   double r_hi;          // largest active lag
+  double inv_rc;        // 2 / r_hi
   double kappa;         // X * r_hi/2: pre-phase turns per unit u
   double tau;           // fine-grid position of target: t = tau * v, v = 2 r / r_hi - 1
   double theta_scale;   // theta = theta_scale * v
@@ -124,8 +125,8 @@ struct DevBuffers {
 void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);  // callback SDFs only
 void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                 hipStream_t st);
-void launch_spread(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, hipStream_t st);
-void launch_interp(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, long long n, hipStream_t st);
+void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st);
+void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, hipStream_t st);
 void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                     unsigned int seq, hipStream_t st);
 
@@ -133,7 +134,7 @@ void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, l
 void launch_seam_spread(const DevConst& dc, const double* nodes, const double* coef, int64_t M, double Cx, double X,
                         double kappa, double2* fft, hipStream_t st);
 void launch_seam_deconv(const DevConst& dc, double2* fft, hipStream_t st);
-void launch_seam_interp(const DevConst& dc, const EsConst& ec, const double2* fft, const double* xs, int64_t n, double Cx, double r_hi,
+void launch_seam_interp(const DevConst& dc, const EsConst* ec, const double2* fft, const double* xs, int64_t n, double Cx, double r_hi,
                         double tau, double theta_scale, double* out_re, double* out_im, hipStream_t st);
 void launch_direct(const double* nodes, const double* coef, int64_t M, const double* xs, int64_t n, double* out_re,
                    double* out_im, hipStream_t st);

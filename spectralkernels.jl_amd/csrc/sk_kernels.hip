@@ -24,14 +24,37 @@ namespace sk {
 
 #define SK_PI 3.14159265358979323846
 
+// (cos, sin)(2 pi t) for |t| <= 1/2 + tiny: quadrant reduction (exact) and the classic degree-13/14
+// minimax kernels on [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos).
+__device__ __forceinline__ double2 cis_turns_small(double t) {
+  const double q = rint(4.0 * t);          // -2 .. 2
+  const double x = (2.0 * SK_PI) * fma(-0.25, q, t);  // |x| <= pi/4, the subtraction is exact
+  const double z = x * x;
+  double ps = 1.58969099521155010221e-10;
+  ps = fma(ps, z, -2.50507602534068634195e-08);
+  ps = fma(ps, z, 2.75573137070700676789e-06);
+  ps = fma(ps, z, -1.98412698298579493134e-04);
+  ps = fma(ps, z, 8.33333333332248946124e-03);
+  ps = fma(ps, z, -1.66666666666666324348e-01);
+  const double sn = fma(x * z, ps, x);
+  double pc = -1.13596475577881948265e-11;
+  pc = fma(pc, z, 2.08757232129817482790e-09);
+  pc = fma(pc, z, -2.75573143513906633035e-07);
+  pc = fma(pc, z, 2.48015872894767294178e-05);
+  pc = fma(pc, z, -1.38888888888741095749e-03);
+  pc = fma(pc, z, 4.16666666666666019037e-02);
+  const double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int qi = (int)q & 3;               // rotate by q quarter turns
+  const double c0 = (qi & 1) ? -sn : cs, s0 = (qi & 1) ? cs : sn;
+  return (qi & 2) ? make_double2(-c0, -s0) : make_double2(c0, s0);
+}
+
 // exp(2 pi i a b) with the product reduced modulo 1 exactly (FMA residual kept).
 __device__ __forceinline__ double2 cis_turns_prod(double a, double b) {
   double p = a * b;
   double e = fma(a, b, -p);
   double fr = p - rint(p);
-  double s, c;
-  sincospi(2.0 * (fr + e), &s, &c);
-  return make_double2(c, s);
+  return cis_turns_small(fr + e);
 }
 
 __device__ __forceinline__ double sdf_eval_dev(int kind, const double* prm, double w) {
@@ -57,6 +80,7 @@ __device__ void set_panel(DevState& s, const DevConst& dc, const double* xs, dou
   pp.X = 0.5 * (pb - pa);
   double r_hi = xs[s.hi - 1];
   pp.r_hi = r_hi;
+  pp.inv_rc = 2.0 / r_hi;
   double xr = pp.X * r_hi;
   pp.kappa = 0.5 * xr;
   pp.tau = xr * (double)dc.n2 / (double)(dc.n1 - dc.w);
@@ -83,12 +107,20 @@ __device__ void tail_scalars(DevState& s, const DevConst& dc) {
       d = dc.tail;
     }
     d -= dc.alpha;
-    const double c = (pow(b, d) * fb) / pow(b, 2.0 * d);
+    // c = sum(ws^d |f|) / sum(ws^(2d)) with all ws == b (src/adaptive.jl:218).  One pow serves every
+    // power of b below: b^(2d) = (b^d)^2, b^(d+k) = b^d b^k -- same under/overflow and NaN behaviour
+    // (0/0 when b^d underflows, e.g. exponential tails), results equal to rounding.
+    const double bd = pow(b, d);
+    const double c = (bd * fb) / (bd * bd);
     if (isnan(c) || isnan(d)) {
-      t.crit = SK_CRIT_PANEL;  // src/adaptive.jl:170-175 (persists: k_advance copies it into s.crit)
+      t.crit = SK_CRIT_PANEL;  // src/adaptive.jl:170-175 (persists: the transition copies it into s.crit)
     } else {
-      t.t1 = -c / (d + dc.dim) * pow(b, d + dc.dim);
-      t.t2num = c * pow(b, d + (dc.dim - 1) * 0.5) / (2.0 * SK_PI);
+      double bdim = b, bhalf = 1.0;  // b^dim and b^((dim-1)/2)
+      for (int q = 1; q < dc.dim; ++q) bdim *= b;
+      if (dc.dim == 2) bhalf = sqrt(b);
+      else if (dc.dim > 2) bhalf = pow(b, (dc.dim - 1) * 0.5);
+      t.t1 = -c / (d + dc.dim) * (bd * bdim);
+      t.t2num = c * (bd * bhalf) / (2.0 * SK_PI);
     }
   }
   s.tail = t;
@@ -115,7 +147,11 @@ __device__ void setup_outer(DevState& s, const DevConst& dc, const double* xs) {
 // truncation_error_estimate (src/adaptive.jl:222-229) for lag x
 __device__ __forceinline__ double trunc_est(const TailScalars& t, double x, int dim) {
   double xp = (dim == 1) ? x : ((dim == 2) ? x * sqrt(x) : pow(x, (dim + 1) * 0.5));
-  return fmin(t.t1, t.t2num / xp);
+  // reciprocal seed + two Newton steps (an error *estimate*: 1 ulp is plenty, full division is 2x the cost)
+  double rcp = __builtin_amdgcn_rcp(xp);
+  rcp = fma(fma(-xp, rcp, 1.0), rcp, rcp);
+  rcp = fma(fma(-xp, rcp, 1.0), rcp, rcp);
+  return fmin(t.t1, t.t2num * rcp);
 }
 
 __device__ __forceinline__ bool step_accept(const DevState& s, double tol) {
@@ -280,7 +316,7 @@ __global__ void __launch_bounds__(64) k_advance(DevConst dc, DevBuffers db, int 
 // pointer and q is a compile-time constant after unrolling, so the coefficient loads are scalar.
 template <int W>
 __device__ __forceinline__ void es_pair(const double* poly, int q, double y2, double& E, double& O) {
-  constexpr int NCO = W / 2 + 2;
+  constexpr int NCO = W / 2 + 1;
   const double* pe = poly + q * 2 * NCO;
   const double* po = pe + NCO;
   E = pe[0];
@@ -292,20 +328,23 @@ __device__ __forceinline__ void es_pair(const double* poly, int q, double y2, do
   }
 }
 
-// Stages the ES tables (kernarg) in LDS; every later read is a same-address LDS broadcast, which
+// Stages the ES tables (device memory, L2-resident; NOT the kernarg segment, which is host-visible
+// memory and slow to read with vector loads) in LDS; every later read is a same-address LDS broadcast, which
 // runs on the LDS pipe beside the FP64 VALU work and costs neither SGPRs nor vector-memory slots.
 template <int W>
-__device__ __forceinline__ void stage_es_tables(const EsConst& ec, double* s_poly, double* s_cheb) {
-  constexpr int NP = (W / 2) * 2 * (W / 2 + 2);
+__device__ __forceinline__ void stage_es_tables(const EsConst* __restrict__ ecp, double* s_poly, double* s_cheb) {
+  const EsConst& ec = *ecp;
+  constexpr int NP = (W / 2) * 2 * (W / 2 + 1);
   const double* gp = ec.poly;
   const double* gc = ec.cheb;
   for (int t = threadIdx.x; t < NP; t += blockDim.x) s_poly[t] = gp[t];
   if (s_cheb)
-    for (int t = threadIdx.x; t < 20; t += blockDim.x) s_cheb[t] = gc[t];
+    for (int t = threadIdx.x; t < 16; t += blockDim.x) s_cheb[t] = gc[t];
 }
 
 // ------------------------------------------------------------------ k_spread (nodes + spreading)
 
+constexpr int kWinCap = 320;     // k_interp: largest FFT-output window (samples per rule) staged in LDS
 constexpr int kTileCells = 64;   // spread-grid cells per workgroup
 constexpr int kSpreadThreads = 256;
 
@@ -355,12 +394,12 @@ __global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mod
 // (lane = cell, the 4 waves split the cell's contiguous source range; deterministic, no atomics).
 // The tile is deconvolved, centred with (-1)^l and written in FFT order.
 template <int W>
-__global__ void __launch_bounds__(kSpreadThreads) k_spread(DevConst dc, EsConst ec, DevBuffers db, int slot) {
+__global__ void __launch_bounds__(kSpreadThreads) k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot) {
   __shared__ double s_w[kSpreadThreads * (W + 1)];
   __shared__ double2 s_c[kSpreadThreads];
   __shared__ int s_l0[kSpreadThreads];
   __shared__ double2 s_red[kSpreadThreads];
-  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 2)];
+  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
   const DevState& s = db.state[slot];
   if (s.done) return;
   const int variant = s.pp.jacobi;
@@ -494,27 +533,24 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread(DevConst dc, EsConst 
 
 // ------------------------------------------------------------------ interpolation core
 
-// F = exp(2 pi i Cx r) * G(v) for both rules: the panel sums sum_j c_j exp(2 pi i w_j r).
+// Index of the first of the W interpolation taps of lag r in the centred FFT output (k_spread
+// multiplies by (-1)^l, so tap q sits at base + q with no wrap-around) and the kernel offset y.
+// Clamped: valid inputs (0 <= r <= r_hi) never need it, but the march may start speculatively on
+// unsorted or invalid lags (kernel_values_device_impl) and must not read out of bounds then.
 template <int W>
-__device__ __forceinline__ void interp_core(const DevConst& dc, const double* s_poly, const double* s_cheb,
-                                            const double2* __restrict__ fft, int nrule, double r,
-                                            double Cx, double r_hi, double tau, double theta_scale, double2& F1,
-                                            double2& F2) {
-  const int n2 = (int)dc.n2;
+__device__ __forceinline__ int tap_base(double r, double r_hi, double inv_rc, double tau, int n2, double& v, double& y) {
   const double Rc = 0.5 * r_hi;
-  const double v = (r - Rc) / Rc;
-  const double t = tau * v;
-  const double tcn = t - 0.5 * W;
+  v = (r - Rc) * inv_rc;  // inv_rc = 2/r_hi from the panel parameters
+  const double tcn = tau * v - 0.5 * W;
   const double k0d = ceil(tcn);
-  const double y = (k0d - tcn) - 0.5;
+  y = (k0d - tcn) - 0.5;
+  return (int)fmin(fmax(k0d, -(double)(n2 / 2)), (double)(n2 / 2 - W)) + n2 / 2;
+}
+
+// The W ES-kernel weights of a lag with kernel offset y (even/odd Horner pairs, LDS tables).
+template <int W>
+__device__ __forceinline__ void es_weights(const double* s_poly, double y, double (&wt)[W]) {
   const double y2 = y * y;
-  // the FFT output is centred (see k_spread): tap q sits at index k0 + q + n2/2, no wrap-around
-  // clamped: valid inputs (0 <= r <= r_hi) never need it, but the march may start speculatively on
-  // unsorted or invalid lags (see kernel_values_device_impl) and must not read out of bounds then
-  int base = (int)fmin(fmax(k0d, -(double)(n2 / 2)), (double)(n2 / 2 - W)) + n2 / 2;
-  const double2* __restrict__ f1 = fft + base;
-  // kernel weights first (24 VGPRs), then the taps: the compiler batches the independent gathers
-  double wt[W];
 #pragma unroll
   for (int q = 0; q < W / 2; ++q) {
     double E, O;
@@ -522,35 +558,47 @@ __device__ __forceinline__ void interp_core(const DevConst& dc, const double* s_
     wt[q] = fma(y, O, E);
     wt[W - 1 - q] = fma(-y, O, E);
   }
+}
+
+// H = sum_q taps[q] * wt[q] for one or two rules (taps: W consecutive FFT-output samples, global or LDS)
+template <int W, bool TWO>
+__device__ __forceinline__ void tap_sums(const double2* taps1, const double2* taps2, const double (&wt)[W], double2& H1,
+                                         double2& H2) {
   double h1r = 0, h1i = 0, h2r = 0, h2i = 0;
 #pragma unroll
   for (int q = 0; q < W; ++q) {
-    const double2 a1 = f1[q];
+    const double2 a1 = taps1[q];
     h1r = fma(a1.x, wt[q], h1r);
     h1i = fma(a1.y, wt[q], h1i);
-    if (nrule > 1) {
-      const double2 a2 = f1[n2 + q];
+    if (TWO) {
+      const double2 a2 = taps2[q];
       h2r = fma(a2.x, wt[q], h2r);
       h2i = fma(a2.y, wt[q], h2i);
     }
   }
-  // 1/phi_hat(theta) by Clenshaw in s = 2 (theta/theta_max)^2 - 1 (scalar coefficient loads)
+  H1 = make_double2(h1r, h1i);
+  H2 = make_double2(h2r, h2i);
+}
+
+// F = exp(2 pi i Cx r) * H / phi_hat(theta): the panel sums sum_j c_j exp(2 pi i w_j r).
+__device__ __forceinline__ void interp_finish(const DevConst& dc, const double* s_cheb, double r, double Cx, double v,
+                                              double theta_scale, double2 H1, double2 H2, double2& F1, double2& F2) {
+  // 1/phi_hat(theta) by Clenshaw in s = 2 (theta/theta_max)^2 - 1 (LDS broadcast coefficient reads)
   const double th = theta_scale * v / dc.theta_max;
   double sarg = 2.0 * th * th - 1.0;
   sarg = sarg > 1.0 ? 1.0 : sarg;
   double b1 = 0.0, b2 = 0.0;
-  const double* cheb = s_cheb;
 #pragma unroll
-  for (int kq = 19; kq >= 1; --kq) {  // ncheb == 20 (sk_tables.cpp)
-    const double b0 = fma(2.0 * sarg, b1, cheb[kq] - b2);
+  for (int kq = 15; kq >= 1; --kq) {  // ncheb == 16 (sk_tables.cpp)
+    const double b0 = fma(2.0 * sarg, b1, s_cheb[kq] - b2);
     b2 = b1;
     b1 = b0;
   }
-  const double invhat = fma(sarg, b1, cheb[0] - b2);
+  const double invhat = fma(sarg, b1, s_cheb[0] - b2);
   const double2 ph = cis_turns_prod(Cx, r);
-  h1r *= invhat; h1i *= invhat; h2r *= invhat; h2i *= invhat;
-  F1 = make_double2(h1r * ph.x - h1i * ph.y, h1r * ph.y + h1i * ph.x);
-  F2 = make_double2(h2r * ph.x - h2i * ph.y, h2r * ph.y + h2i * ph.x);
+  H1.x *= invhat; H1.y *= invhat; H2.x *= invhat; H2.y *= invhat;
+  F1 = make_double2(H1.x * ph.x - H1.y * ph.y, H1.x * ph.y + H1.y * ph.x);
+  F2 = make_double2(H2.x * ph.x - H2.y * ph.y, H2.x * ph.y + H2.y * ph.x);
 }
 
 // One evaluation of the current (sub)panel at the active lags.  Per lag: read r and the confirmed
@@ -561,12 +609,13 @@ __device__ __forceinline__ void interp_core(const DevConst& dc, const double* s_
 // highest lag failing the convergence predicate (src/adaptive.jl:183-198, :231-233), all
 // speculative on this panel being accepted -- k_advance decides.
 template <int W>
-__global__ void __launch_bounds__(256, 4) k_interp(DevConst dc, EsConst ec, DevBuffers db, int slot, long long n) {
+__global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, DevBuffers db, int slot, long long n) {
   __shared__ double smax[4];
   __shared__ unsigned int shi[4];
   __shared__ int sflag[2];
-  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 2)];
-  __shared__ double s_cheb[20];
+  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
+  __shared__ double s_cheb[16];
+  __shared__ double2 s_win[2 * kWinCap];
   // read the needed state fields before any store so that the loads stay scalar
   const DevState& s = db.state[slot];
   if (s.done) return;
@@ -574,36 +623,90 @@ __global__ void __launch_bounds__(256, 4) k_interp(DevConst dc, EsConst ec, DevB
   const TailScalars tail = s.tail;
   const int conf = s.conf, has_acc = s.has_acc, pc = s.pc, p_valid = s.p_valid, stack_len = s.stack_len;
   const double T2 = dc.tol * s.k0abs * 0.5;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long ix1 = s.ix1, hi = s.hi;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if ((long long)blockIdx.x * blockDim.x >= hi) return;
+  const bool act = (i >= ix1 && i < hi);
+  const int n2i = (int)dc.n2;
+  // Ablation (tools/diag/ablate.sh) showed the 2W per-lane 16-B gathers cost 11.5 of 27 us: a wave's
+  // dwordx4 load occupies the vector L1 for 16 cycles whatever the addresses.  The lags are sorted, so
+  // the taps of this workgroup's 256 lags lie in one contiguous window of the FFT output; when it is
+  // small (dense lag sets) it is staged in LDS once, coalesced, and the taps are LDS reads (4 cycles).
+  const long long ia = (long long)blockIdx.x * blockDim.x < ix1 ? ix1 : (long long)blockIdx.x * blockDim.x;
+  const long long ib = ((long long)blockIdx.x + 1) * blockDim.x > hi ? hi - 1 : ((long long)blockIdx.x + 1) * blockDim.x - 1;
+  const double r_a = db.xs[ia], r_b = db.xs[ib];  // scalar loads, in flight together with the lag's own streams
+  double r = 0.0, ck = 0.0, ce = 0.0;
+  if (act) {
+    r = db.xs[i];
+    if (has_acc) {
+      ck = db.accK[conf][i];
+      ce = db.accE[conf][i];
+    }
+  }
   if (threadIdx.x < 2) sflag[threadIdx.x] = 0;
   stage_es_tables<W>(ec, s_poly, s_cheb);
+  int wbase, wsize;
+  {
+    double vv, yy;
+    wbase = tap_base<W>(r_a, pp.r_hi, pp.inv_rc, pp.tau, n2i, vv, yy);
+    wsize = tap_base<W>(r_b, pp.r_hi, pp.inv_rc, pp.tau, n2i, vv, yy) - wbase + W;
+  }
+  const bool use_win = (wsize >= W && wsize <= kWinCap);
+  if (use_win) {
+    for (int j = threadIdx.x; j < wsize; j += blockDim.x) {
+      s_win[j] = db.fft[wbase + j];
+      s_win[kWinCap + j] = db.fft[n2i + wbase + j];
+    }
+  }
   __syncthreads();
-  double e = 0.0;
+  const int o = conf ^ 1;
+  double emax = 0.0;
   int n1f = 0, n2f = 0;
   unsigned int unconv = 0u;
-  if (i >= ix1 && i < hi) {
-    const double r = db.xs[i];
-    const int c = conf, o = conf ^ 1;
-    double Ck = 0.0, Ce = 0.0, Pk = 0.0;
-    if (has_acc) {
-      Ck = db.accK[c][i];
-      Ce = db.accE[c][i];
-    }
-    if (p_valid) Pk = db.P[pc][i];
+  if (act) {
     double2 F1, F2;
-    interp_core<W>(dc, s_poly, s_cheb, db.fft, 2, r, pp.Cx, pp.r_hi, pp.tau, pp.theta_scale, F1, F2);
+    double v, y;
+    const int base = tap_base<W>(r, pp.r_hi, pp.inv_rc, pp.tau, n2i, v, y);
+    double wt[W];
+#if defined(SK_ABL) && SK_ABL == 3
+    for (int q = 0; q < W; ++q) wt[q] = y;
+#else
+    es_weights<W>(s_poly, y, wt);
+#endif
+    double2 H1, H2;
+#if defined(SK_ABL) && SK_ABL == 2
+    H1 = make_double2(wt[0], wt[1]); H2 = make_double2(wt[2], wt[3]);  // ablation: no gathers
+#elif defined(SK_ABL) && SK_ABL == 3
+    H1 = make_double2(y, v); H2 = make_double2(v, y);  // ablation: no weights, no gathers
+#else
+    if (use_win) {
+      int off = base - wbase;
+      off = off < 0 ? 0 : (off > wsize - W ? wsize - W : off);  // only ever clamps on unsorted (speculative) input
+      tap_sums<W, true>(s_win + off, s_win + kWinCap + off, wt, H1, H2);
+    } else {
+      tap_sums<W, true>(db.fft + base, db.fft + n2i + base, wt, H1, H2);
+    }
+#endif
+#if defined(SK_ABL) && SK_ABL == 4
+    F1 = H1; F2 = H2;  // ablation: no Clenshaw / phase
+#else
+    interp_finish(dc, s_cheb, r, pp.Cx, v, pp.theta_scale, H1, H2, F1, F2);
+#endif
     const double scale = dc.c;  // src/quadrature.jl:250-255 (dim == 1)
     const double I1 = (dc.derivative ? F1.y : F1.x) * scale;
     const double I2 = (dc.derivative ? F2.y : F2.x) * scale;
-    e = fabs(I2 - I1);
+    const double e = fabs(I2 - I1);
+    emax = e;
     n1f = isnan(I1);
     n2f = isnan(I2);
-    const double Sk = Ck + I2, Se = Ce + e;
+    const double Sk = ck + I2, Se = ce + e;
+#if defined(SK_ABL) && SK_ABL == 1
+    if (Sk == 1.2345e300) db.accK[o][i] = Sk;  // ablation: (almost) no stores
+#else
     db.accK[o][i] = Sk;
     db.accE[o][i] = Se;
-    const double pk = Pk + I2;
+#endif
+    const double pk = (p_valid ? db.P[pc][i] : 0.0) + I2;
     double te2 = 0.0;
     if (stack_len == 0) {
       const int crit = tail.crit;
@@ -614,11 +717,15 @@ __global__ void __launch_bounds__(256, 4) k_interp(DevConst dc, EsConst ec, DevB
     } else {
       db.P[pc ^ 1][i] = pk;  // needed by the later sub-panels of this outer panel if accepted
     }
+#if defined(SK_ABL) && SK_ABL == 1
+    if (Se == 1.2345e300) db.ks[i] = Sk + te2;
+#else
     db.ks[i] = Sk;
     db.errs[i] = Se + te2;
+#endif
   }
-  // workgroup reductions; NaNs are carried by the flags (fmax drops them)
-  double emax = e;
+  // wave reductions by shuffles (same-address LDS atomics from 64 lanes serialise and were 10 us slower),
+  // then one LDS slot per wave; NaNs are carried by the flags (fmax drops them)
   for (int off = 32; off > 0; off >>= 1) {
     emax = fmax(emax, __shfl_xor(emax, off, 64));
     const unsigned int o2 = __shfl_xor(unconv, off, 64);
@@ -676,15 +783,16 @@ void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long 
                 hipStream_t st) {
   hipLaunchKernelGGL(k_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, mode, t, n, k0, ks0);
 }
-void launch_spread(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, hipStream_t st) {
+void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st) {
   // both variants have their own work list; launch for the longer one (extra blocks zero-pad or idle)
   const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
   const unsigned padblk = nblk(2 * (dc.n2 - dc.n1), kSpreadThreads);
   SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_spread<W>, dim3(tiles + padblk), dim3(kSpreadThreads), 0, st, dc, ec, db,
                                          slot));
 }
-void launch_interp(const DevConst& dc, const EsConst& ec, const DevBuffers& db, int slot, long long n, hipStream_t st) {
-  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_interp<W>, dim3(nblk(n, 256)), dim3(256), 0, st, dc, ec, db, slot, n));
+void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, hipStream_t st) {
+  const unsigned g = nblk(n, 256);
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_interp<W>, dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
 }
 
 // ------------------------------------------------------------------ seam kernels (sk_panel_sums)
@@ -729,17 +837,23 @@ __global__ void k_seam_deconv(DevConst dc, double2* fft) {
 }
 
 template <int W>
-__global__ void __launch_bounds__(256) k_seam_interp(DevConst dc, EsConst ec, const double2* fft, const double* xs, int64_t n,
+__global__ void __launch_bounds__(256) k_seam_interp(DevConst dc, const EsConst* ec, const double2* fft, const double* xs, int64_t n,
                                                       double Cx, double r_hi, double tau, double theta_scale,
                                                       double* out_re, double* out_im) {
-  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 2)];
-  __shared__ double s_cheb[20];
+  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
+  __shared__ double s_cheb[16];
   stage_es_tables<W>(ec, s_poly, s_cheb);
   __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double2 F1, F2;
-  interp_core<W>(dc, s_poly, s_cheb, fft, 1, xs[i], Cx, r_hi, tau, theta_scale, F1, F2);
+  double v, y;
+  const int base = tap_base<W>(xs[i], r_hi, 2.0 / r_hi, tau, (int)dc.n2, v, y);
+  double wt[W];
+  es_weights<W>(s_poly, y, wt);
+  double2 H1, H2;
+  tap_sums<W, false>(fft + base, nullptr, wt, H1, H2);
+  interp_finish(dc, s_cheb, xs[i], Cx, v, theta_scale, H1, H2, F1, F2);
   out_re[i] = F1.x;
   out_im[i] = F1.y;
 }
@@ -779,7 +893,7 @@ void launch_seam_spread(const DevConst& dc, const double* nodes, const double* c
 void launch_seam_deconv(const DevConst& dc, double2* fft, hipStream_t st) {
   hipLaunchKernelGGL(k_seam_deconv, dim3(nblk(dc.n2, 256)), dim3(256), 0, st, dc, fft);
 }
-void launch_seam_interp(const DevConst& dc, const EsConst& ec, const double2* fft, const double* xs, int64_t n, double Cx, double r_hi,
+void launch_seam_interp(const DevConst& dc, const EsConst* ec, const double2* fft, const double* xs, int64_t n, double Cx, double r_hi,
                         double tau, double theta_scale, double* out_re, double* out_im, hipStream_t st) {
   SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_seam_interp<W>, dim3(nblk(n, 256)), dim3(256), 0, st, dc, ec, fft, xs, n, Cx,
                                          r_hi, tau, theta_scale, out_re, out_im));

@@ -58,7 +58,7 @@ void build_es_tables(int w, int64_t n1, int64_t n2, double theta_max, EsTables& 
   else if (w == 4) t.beta = 2.38 * w;
   const ld beta = t.beta;
   // ---- piecewise polynomials, degree 2*nco-1 >= w+1
-  const int nco = (w + 2) / 2 + 1;
+  const int nco = w / 2 + 1;  // degree w+1: at the kernel's own cutoff accuracy exp(-beta)
   const int deg = 2 * nco - 1;
   t.nco = nco;
   t.poly.assign((size_t)(w / 2) * 2 * nco, 0.0);
@@ -109,7 +109,7 @@ void build_es_tables(int w, int64_t n1, int64_t n2, double theta_max, EsTables& 
     t.deconv[l] = (double)(1.0L / hat_eval(h, 2.0L * PI_L * (ld)l / (ld)n2));
   // 1/phi_hat(theta) ~ sum_k cheb[k] T_k(2 (theta/theta_max)^2 - 1)
   t.theta_max = theta_max;
-  const int nc = 20;
+  const int nc = 16;
   t.ncheb = nc;
   t.cheb.assign(nc, 0.0);
   std::vector<ld> fv(nc);

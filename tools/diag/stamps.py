@@ -29,3 +29,13 @@ for lo, hi in ((0, 128), (128, 257), (257, 2000)):
     m = (nsrc >= lo) & (nsrc < hi)
     if m.any():
         print("nsrc in [%d,%d): n=%d mean total %.0f, phases %s" % (lo, hi, m.sum(), tot[m].mean(), d[m].mean(axis=0).round(0)))
+
+b = np.fromfile("/tmp/stamps.bin", dtype=np.uint64).reshape(-1, 8)[4096:]
+b = b[b[:, 0] > 0]
+t = b[:, :4].astype(np.int64)
+rt = (b[:, 5] - b[:, 4]).astype(np.int64)
+cyc = t[:, 3] - t[:, 0]
+print("k_interp blocks", len(b), "cycles/block quantiles", np.percentile(cyc, [0, 50, 90, 100]))
+print("  phases mean: loads+stage %.0f  compute %.0f  reduce %.0f" % ((t[:, 1] - t[:, 0]).mean(), (t[:, 2] - t[:, 1]).mean(), (t[:, 3] - t[:, 2]).mean()))
+print("  realtime ticks (100 MHz) per block median %.0f -> shader clock = %.2f GHz" % (np.median(rt), np.median(cyc / np.maximum(rt, 1)) * 0.1))
+print("  window sizes quantiles", np.percentile(b[:, 6].astype(np.int64), [0, 50, 90, 100]), "use_win frac", b[:, 7].mean())
