@@ -340,13 +340,19 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     }
     for (int r = 0; r < R; ++r) {
       { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, st); }
-      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->d_ec, db, t & 1, st); }
-      {
-        EvScope e(cfg, st, SK_K_FFT);
-        int rc = run_fft(cfg, st);
-        if (rc) return rc;
+      if (cfg->dc.dim == 1) {
+        { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->d_ec, db, t & 1, st); }
+        {
+          EvScope e(cfg, st, SK_K_FFT);
+          int rc = run_fft(cfg, st);
+          if (rc) return rc;
+        }
+        { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->d_ec, db, t & 1, n, st); }
+      } else {
+        // isotropic d-dimensional kernel: direct Bessel sums (src/quadrature.jl:145-160)
+        EvScope e(cfg, st, SK_K_INTERP);
+        launch_bessel(cfg->dc, db, t & 1, n, st);
       }
-      { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->d_ec, db, t & 1, n, st); }
       ++t;
       mode = SK_MODE_TRANSITION;
       stt.n_steps_launched++;
@@ -493,7 +499,8 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   int rc = validate(*args, m, k, warned);
   if (rc) return rc;
   if (args->logw) return fail(SK_EUNSUPPORTED, "logw=true is not implemented on the HIP path yet");
-  if (args->dim != 1) return fail(SK_EUNSUPPORTED, "dim > 1 (Hankel path) is not implemented on the HIP path yet");
+  if (args->dim != 1 && (args->dim % 2 != 0))  // Int64(dim/2-1) is inexact for odd dim (src/quadrature.jl:138,179)
+    return fail(SK_EINVAL, "dim must be 1 or even");
   if (!sk_device_available())
     return fail(SK_ENODEVICE, "no gfx950 device available: the HIP path has no CPU fallback");
   int dev = args->device;

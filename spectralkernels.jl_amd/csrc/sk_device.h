@@ -126,6 +126,7 @@ void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t
 void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                 hipStream_t st);
 void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st);
+void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st);
 void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, hipStream_t st);
 void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                     unsigned int seq, hipStream_t st);

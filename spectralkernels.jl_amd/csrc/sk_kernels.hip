@@ -382,6 +382,10 @@ __global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mod
   }
   const double f = (dc.sdf_kind == SK_SDF_CALLBACK) ? db.fvals[jg] : sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, w);
   const double cj = wq * f;
+  if (dc.dim > 1) {  // Hankel path: k_bessel sums c_j J_nu(2 pi w_j r) directly, it needs the node itself
+    db.src[jg] = make_double2(cj, w);
+    return;
+  }
   const double P = dc.pos[pp.jacobi][rule][j];
   const double u = (P - 0.5 * (double)dc.n1) * dc.delta;
   const double2 ph = cis_turns_prod(pp.kappa, u);
@@ -755,6 +759,118 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
   }
 }
 
+// ------------------------------------------------------------------ k_bessel (dim >= 2)
+
+// Isotropic d-dimensional kernels (src/quadrature.jl:137-161, :176-180, :250-255): the panel sums are
+// sum_j c_j J_nu(2 pi w_j r), nu = dim/2-1 (dim/2 for derivative=true), divided by r^(dim/2-1).  The
+// reference uses a nonuniform fast Hankel transform (FastHankelTransform.jl) above its size cutoff;
+// this first HIP version is the reference's own direct branch (:145-160) -- exact, O(N M), with the
+// node/coefficient tiles staged in LDS.  Everything else (march, acceptance, optimistic outputs)
+// is shared with the dim = 1 path.  Workgroup = 64 lags x 4 source partitions.
+__global__ void __launch_bounds__(256) k_bessel(DevConst dc, DevBuffers db, int slot, long long n) {
+  constexpr int TS = 512;  // sources per LDS tile
+  __shared__ double2 s_src[TS];
+  __shared__ double s_part[2][4][64];
+  __shared__ double smax[4];
+  __shared__ unsigned int shi[4];
+  __shared__ int sflag[2];
+  const DevState& s = db.state[slot];
+  if (s.done) return;
+  const TailScalars tail = s.tail;
+  const int conf = s.conf, has_acc = s.has_acc, pc = s.pc, p_valid = s.p_valid, stack_len = s.stack_len;
+  const double T2 = dc.tol * s.k0abs * 0.5;
+  const long long ix1 = s.ix1, hi = s.hi;
+  if ((long long)blockIdx.x * 64 >= hi) return;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + lane;
+  const bool act = (i >= ix1 && i < hi);
+  const double r = act ? db.xs[i] : 1.0;
+  const double tw = 2.0 * SK_PI * r;
+  const int nu = dc.derivative ? dc.dim / 2 : dc.dim / 2 - 1;  // src/quadrature.jl:179
+  if (threadIdx.x < 2) sflag[threadIdx.x] = 0;
+  double acc[2] = {0.0, 0.0};
+  const int64_t M = dc.M;
+  for (int rule = 0; rule < 2; ++rule) {
+    const int64_t cnt = rule ? 2 * M : M;
+    const double2* __restrict__ src = db.src + (rule ? M : 0);
+    double a = 0.0;
+    for (int64_t jt = 0; jt < cnt; jt += TS) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < TS; t += blockDim.x) s_src[t] = (jt + t < cnt) ? src[jt + t] : make_double2(0.0, 0.0);
+      __syncthreads();
+      if (act) {
+        for (int t = part; t < TS; t += 4) {
+          const double2 cw = s_src[t];
+          const double x = tw * cw.y;
+          const double jv = (nu == 0) ? j0(x) : ((nu == 1) ? j1(x) : jn(nu, x));
+          a = fma(cw.x, jv, a);
+        }
+      }
+    }
+    acc[rule] = a;
+  }
+  s_part[0][part][lane] = acc[0];
+  s_part[1][part][lane] = acc[1];
+  __syncthreads();
+  double emax = 0.0;
+  int n1f = 0, n2f = 0;
+  unsigned int unconv = 0u;
+  if (part == 0 && act) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int q = 0; q < 4; ++q) {  // fixed order
+      s1 += s_part[0][q][lane];
+      s2 += s_part[1][q][lane];
+    }
+    double scale = dc.c;  // src/quadrature.jl:250-255
+    if (dc.dim > 2) scale /= pow(r, dc.dim * 0.5 - 1.0);
+    const double I1 = s1 * scale, I2 = s2 * scale;
+    const double e = fabs(I2 - I1);
+    emax = e;
+    n1f = isnan(I1);
+    n2f = isnan(I2);
+    const int o = conf ^ 1;
+    const double Sk = (has_acc ? db.accK[conf][i] : 0.0) + I2, Se = (has_acc ? db.accE[conf][i] : 0.0) + e;
+    db.accK[o][i] = Sk;
+    db.accE[o][i] = Se;
+    const double pk = (p_valid ? db.P[pc][i] : 0.0) + I2;
+    double te2 = 0.0;
+    if (stack_len == 0) {
+      const int crit = tail.crit;
+      const double te = (crit == SK_CRIT_PANEL) ? 0.0 : trunc_est(tail, r, dc.dim);
+      const bool conv = (crit == SK_CRIT_PANEL || te < T2) && (crit == SK_CRIT_TAILS || fabs(pk) < T2);
+      unconv = conv ? 0u : (unsigned int)(i + 1);
+      te2 = 2.0 * te;
+    } else {
+      db.P[pc ^ 1][i] = pk;
+    }
+    db.ks[i] = Sk;
+    db.errs[i] = Se + te2;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    emax = fmax(emax, __shfl_xor(emax, off, 64));
+    const unsigned int o2 = __shfl_xor(unconv, off, 64);
+    unconv = o2 > unconv ? o2 : unconv;
+  }
+  if (__any(n1f) && lane == 0) atomicOr(&sflag[0], 1);
+  if (__any(n2f) && lane == 0) atomicOr(&sflag[1], 1);
+  if (lane == 0) {
+    smax[part] = emax;
+    shi[part] = unconv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double b = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    unsigned int h = shi[0];
+    for (int w2 = 1; w2 < 4; ++w2) h = shi[w2] > h ? shi[w2] : h;
+    Reductions& rd = db.red[slot];
+    const int a = blockIdx.x & 63;
+    if (b > 0.0) atomicMax(&rd.max_bits[a], (unsigned long long)__double_as_longlong(b));
+    if (h) atomicMax(&rd.hi[a], h);
+    const int f = sflag[0] | (sflag[1] << 1);
+    if (f) atomicOr(&rd.nan, f);
+  }
+}
+
 // ------------------------------------------------------------------ launchers
 
 static inline unsigned nblk(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
@@ -789,6 +905,9 @@ void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, 
   const unsigned padblk = nblk(2 * (dc.n2 - dc.n1), kSpreadThreads);
   SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_spread<W>, dim3(tiles + padblk), dim3(kSpreadThreads), 0, st, dc, ec, db,
                                          slot));
+}
+void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st) {
+  hipLaunchKernelGGL(k_bessel, dim3(nblk(n, 64)), dim3(256), 0, st, dc, db, slot, n);
 }
 void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, hipStream_t st) {
   const unsigned g = nblk(n, 256);

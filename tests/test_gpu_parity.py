@@ -233,3 +233,20 @@ def test_nonpow2_quadspec(sk, oracle):
     for quadspec in [(100, 3), (96, 10), (33, 1)]:
         cfg, ocfg = pair(sk, oracle, "matern", (1, 1, 1.5), quadspec=quadspec)
         check_pair(sk, oracle, cfg, ocfg, rs, np.pi / 2, 1e-8)
+
+
+@pytest.mark.parametrize("derivative", [False, True])
+def test_dim2_direct_bessel_path(sk, oracle, derivative):
+    # dim = 2 (scripts/simple_2d.jl, test/matern_sdf.jl dim=2, test/derivatives/nll_2d.jl): direct Bessel
+    # sums on the device (the reference's branch src/quadrature.jl:145-160) against the oracle
+    parms = (0.7, 1.3, 1.8)
+    rs = np.concatenate([[0.0], np.linspace(0.001, 1.1, 60)])
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, 2), dim=2, derivative=derivative, quadspec=(64, 8))
+    ocfg = oracle.AdaptiveKernelConfig(oracle.SDF.matern(*parms, 2), dim=2, derivative=derivative, quadspec=(64, 8))
+    k0 = float(oracle.matern_cov(0.0, parms, d=2))
+    ks, errs = check_pair(sk, oracle, cfg, ocfg, rs, k0, 1e-8)
+    if not derivative:
+        assert np.abs(ks - oracle.matern_cov(rs, parms, d=2)).max() / k0 <= 10 * 1e-8
+        assert abs(sk.compute_k0(cfg) / k0 - 1) < 1e-7  # Bessel small-r limit factor, src/adaptive.jl:84-86
+    with pytest.raises(sk.SpectralKernelsError):
+        sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, 3), dim=3)
