@@ -350,6 +350,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->d_ec, db, t & 1, n, st); }
       } else {
         // isotropic d-dimensional kernel: direct Bessel sums (src/quadrature.jl:145-160)
+        if (!cb) launch_tail(cfg->dc, db, t & 1, st);
         EvScope e(cfg, st, SK_K_INTERP);
         launch_bessel(cfg->dc, db, t & 1, n, st);
       }

@@ -74,7 +74,7 @@ struct DevState {
   // outer panel's accepted sub-panel sums, src/adaptive.jl:183-198 uses them) is only
   // materialised while an outer panel is being bisected: buffer `pc`, valid iff p_valid.
   int conf, has_acc, pc, p_valid;
-  int crit, done, stack_len, pad0;
+  int crit, done, stack_len, tail_pending;
   unsigned long long max_err_bits;  // atomicMax over the bit pattern of |I2-I1| >= 0
   unsigned long long hi_new;        // atomicMax over i+1 of unconverged lags
   int nan1, nan2;

@@ -135,10 +135,10 @@ __device__ void setup_outer(DevState& s, const DevConst& dc, const double* xs) {
     s.b = b;
     s.n_outer += 1;
     set_panel(s, dc, xs, a, b);
-    if (dc.sdf_kind != SK_SDF_CALLBACK) {
-      s.fb = sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, b);
-      tail_scalars(s, dc);
-    }
+    // S(b) and the tail fit (pow/log chain, ~3 us of single-thread latency) are not needed before
+    // k_interp: they are computed off the critical path by one otherwise idle workgroup of k_spread
+    // (k_bessel for dim > 1; k_tail for callback SDFs)
+    s.tail_pending = 1;
   } else {
     s.done = 1;
   }
@@ -287,11 +287,18 @@ __device__ void step_state(DevState& sh, const DevConst& dc, const DevBuffers& d
   __syncthreads();
 }
 
-// Callback SDFs: the host uploads S(b) into state.fb before the step, then this computes the tail.
-__global__ void k_tail(DevConst dc, DevBuffers db, int slot) {
-  DevState& s = db.state[slot];
-  if (s.done) return;
+// Deferred tail fit of a new outer panel (see setup_outer).
+__device__ void resolve_tail(DevState& s, const DevConst& dc) {
+  if (s.done || !s.tail_pending) return;
+  if (dc.sdf_kind != SK_SDF_CALLBACK) s.fb = sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, s.b);
   tail_scalars(s, dc);
+  s.tail_pending = 0;
+}
+
+// Callback SDFs: the host uploads S(b) into state.fb before the step, then this computes the tail.
+// Also used by the dim > 1 path.
+__global__ void k_tail(DevConst dc, DevBuffers db, int slot) {
+  resolve_tail(db.state[slot], dc);
 }
 
 // Round boundary: materialises state_t for the host (pinned, host-mapped status block) without
@@ -411,6 +418,7 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread(DevConst dc, const Es
   const int ntiles = dc.ntiles[variant];
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= ntiles) {
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) resolve_tail(db.state[slot], dc);  // off the critical path
     // zero padding of the FFT input: indices [n1 - n1/2, n2 - n1/2) of both rules
     const int64_t npad = n2 - n1;
     int64_t g = ((int64_t)blockIdx.x - ntiles) * kSpreadThreads + tid;
