@@ -314,6 +314,8 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   db.P[1] = db.P[0] + n;
   db.fvals = cfg->d_fvals;
   const bool cb = (cfg->dc.sdf_kind == SK_SDF_CALLBACK);
+  db.check_input = (check_flags && !cb) ? 1 : 0;
+  if (check_flags && cb) launch_check_sorted(d_uxs, n, db.flags, st);  // callback SDFs never run k_gen in INIT mode
   sk_stats& stt = cfg->stats;
   const DevState* hs = &cfg->h_status->state;
   int t = 0;             // step counter: step t evaluates the panel described by state_t
@@ -422,7 +424,6 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   if (rc) return rc;
   // The input is checked for "strictly increasing, >= 0" on the device and the march starts
   // speculatively on it as is; the flags come back with the first status block (no extra sync).
-  launch_check_sorted(d_xs, (long long)n, cfg->db.flags, st);
   cfg->stats.n_unique = (int64_t)n;
   rc = run_core(cfg, d_xs, (long long)n, k0, ks0, d_vals, d_errs, (double*)cfg->ws, st, true);
   const int unsorted = cfg->h_status->flags[0], invalid = cfg->h_status->flags[1];

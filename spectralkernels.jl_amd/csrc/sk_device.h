@@ -117,7 +117,8 @@ struct DevBuffers {
   // highest unconverged lag + 1, NaN flags (bit 0: I1, bit 1: I2)
   Reductions* red;          // 2 slots (step parity)
   HostStatus* host_status;  // device view of the pinned status block
-  int* flags;               // k_check_sorted flags (reset by k_advance once reported)
+  int* flags;               // input-check flags: [0] not strictly increasing, [1] negative or NaN lag
+  int check_input;          // 1: the first k_gen of this call checks the lags (speculative sorted path)
   unsigned long long* stamps;  // diagnostic builds only (SK_STAMPS): 8 words per k_spread workgroup
 };
 

@@ -335,9 +335,9 @@ __device__ __forceinline__ void es_pair(const double* poly, int q, double y2, do
   }
 }
 
-// Stages the ES tables (device memory, L2-resident; NOT the kernarg segment, which is host-visible
-// memory and slow to read with vector loads) in LDS; every later read is a same-address LDS broadcast, which
-// runs on the LDS pipe beside the FP64 VALU work and costs neither SGPRs nor vector-memory slots.
+// Stages the ES tables (device memory) in LDS for k_spread, whose table reads come after LDS/global
+// stores.  k_interp reads them with scalar loads instead: a same-address LDS broadcast still returns
+// 16 B to every lane, and ~50 of them per wave cost as much LDS bandwidth as all the FP64 VALU work.
 template <int W>
 __device__ __forceinline__ void stage_es_tables(const EsConst* __restrict__ ecp, double* s_poly, double* s_cheb) {
   const EsConst& ec = *ecp;
@@ -362,6 +362,18 @@ __global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mod
                                              double ks0) {
   __shared__ DevState sh;
   step_state(sh, dc, db, mode, t, n, k0, ks0);
+  if (mode == SK_MODE_INIT && db.check_input) {
+    // src/adaptive.jl:99,113: is the input strictly increasing (=> already unique and sorted) and valid?
+    // Folded into the first k_gen (grid-stride over the lags) instead of a launch of its own.
+    bool bad = false, unsorted = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+      const double x = db.xs[i];
+      bad |= !(x >= 0.0);
+      unsorted |= (i + 1 < n) && !(x < db.xs[i + 1]);
+    }
+    if (__any(unsorted) && (threadIdx.x & 63) == 0) atomicOr(&db.flags[0], 1);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&db.flags[1], 1);
+  }
   if (sh.done) return;
   const PanelParams pp = sh.pp;
   const int64_t M = dc.M;
@@ -625,8 +637,6 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
   __shared__ double smax[4];
   __shared__ unsigned int shi[4];
   __shared__ int sflag[2];
-  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
-  __shared__ double s_cheb[16];
   __shared__ double2 s_win[2 * kWinCap];
   // read the needed state fields before any store so that the loads stay scalar
   const DevState& s = db.state[slot];
@@ -656,7 +666,6 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
     }
   }
   if (threadIdx.x < 2) sflag[threadIdx.x] = 0;
-  stage_es_tables<W>(ec, s_poly, s_cheb);
   int wbase, wsize;
   {
     double vv, yy;
@@ -683,7 +692,7 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
 #if defined(SK_ABL) && SK_ABL == 3
     for (int q = 0; q < W; ++q) wt[q] = y;
 #else
-    es_weights<W>(s_poly, y, wt);
+    es_weights<W>(ec->poly, y, wt);  // wave-uniform addresses, loaded before any store: scalar loads
 #endif
     double2 H1, H2;
 #if defined(SK_ABL) && SK_ABL == 2
@@ -702,7 +711,7 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
 #if defined(SK_ABL) && SK_ABL == 4
     F1 = H1; F2 = H2;  // ablation: no Clenshaw / phase
 #else
-    interp_finish(dc, s_cheb, r, pp.Cx, v, pp.theta_scale, H1, H2, F1, F2);
+    interp_finish(dc, ec->cheb, r, pp.Cx, v, pp.theta_scale, H1, H2, F1, F2);
 #endif
     const double scale = dc.c;  // src/quadrature.jl:250-255 (dim == 1)
     const double I1 = (dc.derivative ? F1.y : F1.x) * scale;
