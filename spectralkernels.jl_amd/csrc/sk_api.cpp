@@ -75,6 +75,8 @@ struct sk_config {
   // per-call workspace (grow only)
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  double* d_io = nullptr;          // staging of sk_kernel_values (host arrays)
+  size_t io_bytes = 0;
   HostStatus* h_status = nullptr;  // pinned + device-mapped, written by k_advance
   unsigned int seq = 0;
   size_t trace_len = 0;
@@ -662,6 +664,7 @@ void sk_config_destroy(sk_config* cfg) {
   if (cfg->fft_work) hipFree(cfg->fft_work);
   for (void* p : cfg->owned) hipFree(p);
   if (cfg->ws) hipFree(cfg->ws);
+  if (cfg->d_io) hipFree(cfg->d_io);
   if (cfg->h_status) hipHostFree(cfg->h_status);
   if (cfg->h_nuniq) hipHostFree(cfg->h_nuniq);
   if (cfg->own_stream) hipStreamDestroy(cfg->own_stream);
@@ -717,8 +720,15 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
   }
   if (n == 0) return SK_OK;
   HIPCHK(hipSetDevice(cfg->device));
-  double* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, 3 * n * sizeof(double)));
+  // grow-only device staging buffer of the host-array entry (lags, values, errors)
+  if (3 * n * sizeof(double) > cfg->io_bytes) {
+    if (cfg->d_io) HIPCHK(hipFree(cfg->d_io));
+    cfg->d_io = nullptr;
+    cfg->io_bytes = 0;
+    HIPCHK(hipMalloc((void**)&cfg->d_io, 3 * n * sizeof(double) + 3 * n * sizeof(double) / 4));
+    cfg->io_bytes = 3 * n * sizeof(double) + 3 * n * sizeof(double) / 4;
+  }
+  double* d = cfg->d_io;
   hipStream_t st = cfg->own_stream;
   int rc = SK_OK;
   if (hipMemcpyAsync(d, xs, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
@@ -730,7 +740,6 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
         hipStreamSynchronize(st) != hipSuccess)
       rc = fail(SK_EHIP, "D2H copy failed");
   }
-  hipFree(d);
   return rc;
 }
 
