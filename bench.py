@@ -25,6 +25,9 @@ WORKLOADS = {
     # name: (sdf kind, params, config kwargs, r-grid builder, k0, truth)
     "C2": dict(desc="Matern nu=3/2 S=(1+w^2)^-2, 1e6 log-spaced r in [1e-6,1], tol=1e-8, quadspec=(4096,16)",
                sdf=("matern", (1.0, 1.0, 1.5)), kw=dict(tol=1e-8), n=10 ** 6, lo=-6.0, hi=0.0),
+    "C4": dict(desc="dim=2 isotropic S=0.7(1.3^2+w^2)^-2.8 (scripts/simple_2d.jl), 1e6 pairwise lags |x_i-y_j| of 1e3 x 1e3 "
+                    "splitmix64-seeded uniform points in [0,1]^2, tol=1e-8, quadspec=(4096,16); direct Bessel-sum kernel",
+               sdf=("matern", (0.7, 1.3, 1.8, 2.0)), kw=dict(tol=1e-8, dim=2), n=10 ** 6, lo=None, hi=None),
     "C5": dict(desc="Matern (2.14,0.97,0.89), 1e5 uniform r in [0,5.1], tol=1e-12, quadspec=(256,16)",
                sdf=("matern", (2.14, 0.97, 0.89)), kw=dict(tol=1e-12, quadspec=(256, 16)), n=10 ** 5, lo=None, hi=5.1),
     "C3": dict(desc="singular long-memory SDF alpha=0.4 (rho=10, nu=0.5, K(0)=1), 1e6 log-spaced r in [1e-8,1e-2], "
@@ -33,9 +36,31 @@ WORKLOADS = {
 }
 
 
+def splitmix64(seed, count):
+    """Documented deterministic stream: splitmix64 -> uniform doubles in [0,1)."""
+    out = np.empty(count)
+    x = np.uint64(seed)
+    with np.errstate(over="ignore"):
+        for i in range(count):
+            x = x + np.uint64(0x9E3779B97F4A7C15)
+            z = x
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            out[i] = float(z >> np.uint64(11)) * (1.0 / 9007199254740992.0)
+    return out
+
+
 def shard_grid(w, rank, world):
     """Rank `rank` of `world` gets every world-th lag of the world*n log-spaced global grid."""
     n = w["n"]
+    if w["hi"] is None:  # C4: pairwise distances between two seeded point sets, rows of X sharded over ranks
+        m = int(round(np.sqrt(n)))
+        u = splitmix64(123, 4 * m).reshape(4, m)
+        X, Y = np.stack([u[0], u[1]], 1), np.stack([u[2], u[3]], 1)
+        rows = np.arange(rank, m, world) if world > 1 else np.arange(m)
+        d = np.sqrt(((X[rows, None, :] - Y[None, :, :]) ** 2).sum(-1)).ravel()
+        return np.ascontiguousarray(d)
     if w["lo"] is None:  # uniform grid including r = 0 (test/matern_sdf.jl:5)
         g = np.linspace(0.0, w["hi"], n * world)
     else:
@@ -113,7 +138,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps
-    value = world * n / (dt / args.steps)
+    n_all = n
+    if dist is not None and args.workload == "C4":  # sharded fixed problem: count every rank's lags
+        tn = torch.tensor([n], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tn)
+        n_all = int(tn.item())
+        value = n_all / (dt / args.steps)
+    else:
+        value = world * n / (dt / args.steps)
 
     # ---- accuracy of this rank's shard against the closed form
     ks = d_ks.cpu().numpy()
@@ -121,9 +153,10 @@ def main():
     if args.workload == "C2":
         truth = k0 * (1 + 2 * np.pi * rs) * np.exp(-2 * np.pi * rs)
         max_rel_err = float(np.abs(ks - truth).max() / abs(k0))
-    elif args.workload == "C5":
+    elif args.workload in ("C4", "C5"):
         from oracle import sk_oracle as o
-        max_rel_err = float(np.abs(ks - o.matern_cov(rs, prm)).max() / abs(k0))
+        d = 2 if args.workload == "C4" else 1
+        max_rel_err = float(np.abs(ks - o.matern_cov(rs, prm[:3], d=d)).max() / abs(k0))
     else:
         max_rel_err = None
 
@@ -219,7 +252,7 @@ def main():
     if rank == 0:
         out = {"metric": "r-targets/sec at tol=%g" % w["kw"]["tol"], "value": value, "unit": "r-targets/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "scaling": "strong" if args.workload == "C4" else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": args.workload + ": " + w["desc"], "lags_per_gpu": n,
                           "sharding": "r-set strided over ranks, K(0) all-reduce at set-up only",
                           "nufft_width": cfg.nufft_width},
