@@ -62,7 +62,7 @@ typedef struct {
   void* f_ctx;
   sk_sdf_batch_fn df;      /* derivative of the SDF; only needed for logw (unsupported yet) */
   void* df_ctx;
-  int dim;                 /* 1 (cos/sin kernel); even dims go through the Bessel path */
+  int dim;                 /* 1 (cos/sin kernel); even dims: Bessel kernels (fast Hankel transform or direct sums) */
   double alpha;            /* |w|^-alpha singularity at the origin */
   double tol;              /* relative to K(0) */
   int derivative;          /* K'(r) */
@@ -73,6 +73,8 @@ typedef struct {
   int64_t m, k;            /* quadspec: k sub-panels of m (and 2m) Gauss nodes per NUFFT */
   int device;              /* HIP device ordinal; -1 = current device */
   int nufft_width;         /* 0 = choose from tol; else spreading width w in [4,16] */
+  int hankel_min_lags;     /* dim >= 2: use the fast Hankel transform for >= this many unique lags, the direct
+                              Bessel-sum kernel below (0 = default 2048; -1 = always direct) */
 } sk_config_args;
 
 typedef struct sk_config sk_config; /* opaque */

@@ -17,7 +17,7 @@ class ConfigArgs(C.Structure):
                 ("df", SDF_BATCH_FN), ("df_ctx", C.c_void_p), ("dim", C.c_int), ("alpha", C.c_double),
                 ("tol", C.c_double), ("derivative", C.c_int), ("logw", C.c_int), ("criteria", C.c_int),
                 ("has_tail", C.c_int), ("tail", C.c_double), ("m", C.c_int64), ("k", C.c_int64),
-                ("device", C.c_int), ("nufft_width", C.c_int)]
+                ("device", C.c_int), ("nufft_width", C.c_int), ("hankel_min_lags", C.c_int)]
 
 
 class Stats(C.Structure):

@@ -57,7 +57,8 @@ def _check(code):
     return code
 
 
-def _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, tail, quadspec, device, nufft_width):
+def _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, tail, quadspec, device, nufft_width,
+               hankel_min_lags=0):
     if not isinstance(f, SDF):
         f = SDF.callback(f)
     if convergence_criteria not in _CRIT:
@@ -91,6 +92,7 @@ def _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, t
     a.m, a.k = int(quadspec[0]), int(quadspec[1])
     a.device = int(device)
     a.nufft_width = int(nufft_width)
+    a.hankel_min_lags = int(hankel_min_lags)
     return a, keep, f
 
 
@@ -99,11 +101,12 @@ class AdaptiveKernelConfig:
     quadspec) -- src/adaptive.jl:24-59.  Owns a device-side config handle."""
 
     def __init__(self, f, df=None, dim=1, alpha=0.0, tol=1e-8, derivative=False, logw=False,
-                 convergence_criteria="both", tail=None, quadspec=(2 ** 12, 2 ** 4), device=-1, nufft_width=0):
+                 convergence_criteria="both", tail=None, quadspec=(2 ** 12, 2 ** 4), device=-1, nufft_width=0,
+                 hankel_min_lags=0):
         self._h = None
         lib = L.load()
         args, self._keep, self.f = _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, tail,
-                                              quadspec, device, nufft_width)
+                                              quadspec, device, nufft_width, hankel_min_lags)
         self._args = args
         h = C.c_void_p()
         code = _check(lib.sk_config_create(C.byref(h), C.byref(args)))

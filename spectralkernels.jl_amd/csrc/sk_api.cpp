@@ -69,6 +69,10 @@ struct sk_config {
   DevBuffers db;
   std::vector<void*> owned;  // device allocations freed at destroy
   rocfft_plan plan = nullptr;
+  rocfft_plan plan_hk = nullptr;   // batch 2*kHkTerms, Hankel path
+  void* fft_work_hk = nullptr;
+  rocfft_execution_info info_hk = nullptr;
+  double hk_a[kHkTerms];
   rocfft_execution_info info = nullptr;
   void* fft_work = nullptr;
   double* d_fvals = nullptr;
@@ -316,15 +320,19 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   db.P[1] = db.P[0] + n;
   db.fvals = cfg->d_fvals;
   const bool cb = (cfg->dc.sdf_kind == SK_SDF_CALLBACK);
-  db.check_input = (check_flags && !cb) ? 1 : 0;
-  if (check_flags && cb) launch_check_sorted(d_uxs, n, db.flags, st);  // callback SDFs never run k_gen in INIT mode
+  // dim >= 2: fast Hankel transform (host-driven per step: the level split depends on r_hi) or direct sums
+  const int hk_min = cfg->args.hankel_min_lags == 0 ? 2048 : cfg->args.hankel_min_lags;
+  const bool hankel = cfg->dc.dim > 1 && hk_min > 0 && n >= hk_min;
+  const bool host_step = cb || hankel;  // the host needs state_t before each step
+  db.check_input = (check_flags && !host_step) ? 1 : 0;
+  if (check_flags && host_step) launch_check_sorted(d_uxs, n, db.flags, st);  // k_gen never runs in INIT mode here
   sk_stats& stt = cfg->stats;
   const DevState* hs = &cfg->h_status->state;
   int t = 0;             // step counter: step t evaluates the panel described by state_t
   int mode = SK_MODE_INIT;
-  int R = cb ? 1 : 2;
+  int R = host_step ? 1 : 2;
   for (;;) {
-    if (cb) {
+    if (host_step) {
       // host closure: needs state_t (panel bounds) before the step can be generated
       const unsigned int seq = ++cfg->seq;
       launch_advance(cfg->dc, db, mode, t, n, k0, ks0, seq, st);
@@ -332,15 +340,52 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       if (rc) return rc;
       if (check_flags && (cfg->h_status->flags[0] || cfg->h_status->flags[1])) return SK_OK;
       if (hs->done) break;
-      host_nodes(cfg, hs->pp, cfg->h_nodes);
-      cfg->h_fvals.resize(cfg->h_nodes.size());
-      cfg->sdf.batch(cfg->h_nodes.data(), cfg->h_fvals.data(), cfg->h_nodes.size());
-      HIPCHK(hipMemcpyAsync(cfg->d_fvals, cfg->h_fvals.data(), sizeof(double) * cfg->h_fvals.size(),
-                            hipMemcpyHostToDevice, st));
-      double fb = cfg->sdf(hs->b);
-      HIPCHK(hipMemcpyAsync(&db.state[t & 1].fb, &fb, sizeof(double), hipMemcpyHostToDevice, st));
+      if (cb) {
+        host_nodes(cfg, hs->pp, cfg->h_nodes);
+        cfg->h_fvals.resize(cfg->h_nodes.size());
+        cfg->sdf.batch(cfg->h_nodes.data(), cfg->h_fvals.data(), cfg->h_nodes.size());
+        HIPCHK(hipMemcpyAsync(cfg->d_fvals, cfg->h_fvals.data(), sizeof(double) * cfg->h_fvals.size(),
+                              hipMemcpyHostToDevice, st));
+        double fb = cfg->sdf(hs->b);
+        HIPCHK(hipMemcpyAsync(&db.state[t & 1].fb, &fb, sizeof(double), hipMemcpyHostToDevice, st));
+      }
       launch_tail(cfg->dc, db, t & 1, st);
       mode = SK_MODE_ASIS;
+    }
+    if (hankel) {
+      // ---- one step of the Hankel path (see "nonuniform fast Hankel transform" in sk_kernels.hip)
+      HankelPlan hp;
+      std::memset(&hp, 0, sizeof(hp));
+      hp.nu = cfg->dc.derivative ? cfg->dc.dim / 2 : cfg->dc.dim / 2 - 1;
+      std::memcpy(hp.a, cfg->hk_a, sizeof(hp.a));
+      const double r_hi = hs->pp.r_hi, pb = hs->pp.pb;
+      int L = 0;
+      while (L < kHkMaxLevels - 1 && kHkZ0 * std::pow(kHkBeta, L + 1) / (2.0 * M_PI * r_hi) < pb) ++L;
+      hp.L = L;
+      for (int l = 0; l <= L; ++l) {
+        hp.edge[l] = r_hi / std::pow(kHkBeta, l);
+        hp.om[l] = (l < L) ? kHkZ0 * std::pow(kHkBeta, l + 1) / (2.0 * M_PI * r_hi) : INFINITY;
+      }
+      hp.edge[0] = r_hi;
+      hp.edge[L + 1] = 0.0;
+      { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, st); }
+      launch_hk_near(cfg->dc, db, hp, st);
+      for (int l = 0; l < L; ++l) {
+        launch_hk_gen(cfg->dc, db, hp, l, t & 1, st);
+        { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, st); }
+        {
+          EvScope e(cfg, st, SK_K_FFT);
+          FFTCHK(rocfft_execution_info_set_stream(cfg->info_hk, st));
+          void* in[1] = {db.hk_fft};
+          FFTCHK(rocfft_execute(cfg->plan_hk, in, nullptr, cfg->info_hk));
+        }
+        { EvScope e(cfg, st, SK_K_INTERP); launch_hk_interp(cfg->dc, cfg->d_ec, db, hp, l, t & 1, n, st); }
+      }
+      { EvScope e(cfg, st, SK_K_INTERP); launch_hk_interp(cfg->dc, cfg->d_ec, db, hp, L, t & 1, n, st); }
+      ++t;
+      mode = SK_MODE_TRANSITION;
+      stt.n_steps_launched++;
+      continue;
     }
     for (int r = 0; r < R; ++r) {
       { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, st); }
@@ -353,7 +398,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         }
         { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->d_ec, db, t & 1, n, st); }
       } else {
-        // isotropic d-dimensional kernel: direct Bessel sums (src/quadrature.jl:145-160)
+        // isotropic d-dimensional kernel, few lags: direct Bessel sums (src/quadrature.jl:145-160)
         if (!cb) launch_tail(cfg->dc, db, t & 1, st);
         EvScope e(cfg, st, SK_K_INTERP);
         launch_bessel(cfg->dc, db, t & 1, n, st);
@@ -362,7 +407,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       mode = SK_MODE_TRANSITION;
       stt.n_steps_launched++;
     }
-    if (!cb) {
+    if (!host_step) {
       const unsigned int seq = ++cfg->seq;
       { EvScope e(cfg, st, SK_K_ADVANCE); launch_advance(cfg->dc, db, mode, t, n, k0, ks0, seq, st); }
       int rc = wait_status(cfg, seq, st);
@@ -646,6 +691,39 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     }
     rocfft_execution_info_set_work_buffer(cfg->info, cfg->fft_work, wb);
   }
+  if (args->dim > 1) {
+    // Hankel path: batched plan for the K asymptotic terms x 2 rules, buffers, a_k(nu)
+    size_t len2[1] = {(size_t)dc.n2};
+    if (rocfft_plan_create(&cfg->plan_hk, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+                           rocfft_precision_double, 1, len2, 2 * kHkTerms, nullptr) != rocfft_status_success) {
+      sk_config_destroy(cfg);
+      return fail(SK_EHIP, "rocfft_plan_create (Hankel batch) failed");
+    }
+    size_t wb2 = 0;
+    rocfft_plan_get_work_buffer_size(cfg->plan_hk, &wb2);
+    rocfft_execution_info_create(&cfg->info_hk);
+    if (wb2) {
+      if (hipMalloc(&cfg->fft_work_hk, wb2) != hipSuccess) {
+        sk_config_destroy(cfg);
+        return fail(SK_EHIP, "hipMalloc(fft work) failed");
+      }
+      rocfft_execution_info_set_work_buffer(cfg->info_hk, cfg->fft_work_hk, wb2);
+    }
+    void* p1 = nullptr; void* p2 = nullptr; void* p3 = nullptr; void* p4 = nullptr;
+    if (hipMalloc(&p1, sizeof(double2) * (size_t)kHkTerms * 3 * cfg->M) != hipSuccess ||
+        hipMalloc(&p2, sizeof(double2) * (size_t)kHkTerms * 2 * dc.n2) != hipSuccess ||
+        hipMalloc(&p3, sizeof(double) * (size_t)(kHkMaxLevels + 1) * 2 * kHkNodes) != hipSuccess ||
+        hipMalloc(&p4, sizeof(double) * (size_t)(kHkMaxLevels + 1) * 2 * kHkNodes) != hipSuccess) {
+      sk_config_destroy(cfg);
+      return fail(SK_EHIP, "hipMalloc(Hankel buffers) failed");
+    }
+    cfg->owned.push_back(p1); cfg->owned.push_back(p2); cfg->owned.push_back(p3); cfg->owned.push_back(p4);
+    db.hk_src = (double2*)p1; db.hk_fft = (double2*)p2; db.hk_nodes = (double*)p3; db.hk_cheb = (double*)p4;
+    const int nu = args->derivative ? args->dim / 2 : args->dim / 2 - 1;
+    cfg->hk_a[0] = 1.0;
+    for (int kq = 1; kq < kHkTerms; ++kq)
+      cfg->hk_a[kq] = cfg->hk_a[kq - 1] * (4.0 * nu * nu - (2.0 * kq - 1.0) * (2.0 * kq - 1.0)) / (8.0 * kq);
+  }
   *out = cfg;
   if (warned) {
     set_error(
@@ -660,6 +738,9 @@ void sk_config_destroy(sk_config* cfg) {
   if (!cfg) return;
   hipSetDevice(cfg->device);
   if (cfg->plan) rocfft_plan_destroy(cfg->plan);
+  if (cfg->plan_hk) rocfft_plan_destroy(cfg->plan_hk);
+  if (cfg->info_hk) rocfft_execution_info_destroy(cfg->info_hk);
+  if (cfg->fft_work_hk) hipFree(cfg->fft_work_hk);
   if (cfg->info) rocfft_execution_info_destroy(cfg->info);
   if (cfg->fft_work) hipFree(cfg->fft_work);
   for (void* p : cfg->owned) hipFree(p);

@@ -10,6 +10,23 @@ constexpr int kMaxNco = kMaxWidth / 2 + 1;
 constexpr int kMaxCheb = 24;
 constexpr int kStackCap = 5000;  // src/quadrature.jl:7
 constexpr int kTraceCap = 4096;
+// nonuniform fast Hankel transform (dim >= 2): level-split asymptotic expansion
+constexpr int kHkTerms = 16;     // K terms of the Hankel asymptotic series (valid for z >= kHkZ0)
+constexpr int kHkNodes = 160;    // Chebyshev nodes of the near-field interpolant per lag level
+constexpr int kHkMaxLevels = 12; // lag levels (ratio kHkBeta) incl. the innermost near-only one
+constexpr double kHkZ0 = 24.0;
+constexpr double kHkBeta = 8.0;
+
+// One step of the Hankel path: lag levels l = 0..L (level L is near-only).  Level l < L covers lags in
+// (edge[l+1], edge[l]], treats sources w >= om[l] by the asymptotic series and w < om[l] by the
+// Chebyshev interpolant on that lag interval.
+struct HankelPlan {
+  int L;                       // number of far levels
+  int nu;                      // Bessel order
+  double edge[kHkMaxLevels + 2];  // edge[0] = r_hi (inclusive top), edge[L+1] = 0
+  double om[kHkMaxLevels + 1];    // far/near source threshold per level (om[L] = +inf)
+  double a[kHkTerms];          // asymptotic coefficients a_k(nu)
+};
 
 // Per-config constants, passed to kernels by value.
 struct DevConst {
@@ -119,6 +136,11 @@ struct DevBuffers {
   HostStatus* host_status;  // device view of the pinned status block
   int* flags;               // input-check flags: [0] not strictly increasing, [1] negative or NaN lag
   int check_input;          // 1: the first k_gen of this call checks the lags (speculative sorted path)
+  // Hankel path (dim >= 2)
+  double2* hk_src;          // kHkTerms x 3M scaled, pre-phased source strengths of the current level
+  double2* hk_fft;          // kHkTerms x 2 x n2 complex grids of the current level
+  double* hk_nodes;         // (kHkMaxLevels+1) x 2 x kHkNodes near sums at the Chebyshev nodes
+  double* hk_cheb;          // same shape: Chebyshev coefficients
   unsigned long long* stamps;  // diagnostic builds only (SK_STAMPS): 8 words per k_spread workgroup
 };
 
@@ -128,6 +150,11 @@ void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long 
                 hipStream_t st);
 void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st);
 void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st);
+void launch_hk_gen(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, int level, int slot, hipStream_t st);
+void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st);
+void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st);
+void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HankelPlan& hp, int level, int slot,
+                      long long n, hipStream_t st);
 void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, hipStream_t st);
 void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                     unsigned int seq, hipStream_t st);

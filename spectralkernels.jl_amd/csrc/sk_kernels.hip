@@ -888,6 +888,222 @@ __global__ void __launch_bounds__(256) k_bessel(DevConst dc, DevBuffers db, int 
   }
 }
 
+// ------------------------------------------------------------------ nonuniform fast Hankel transform
+
+// The reference calls FastHankelTransform.jl's nufht above its size cutoff (src/quadrature.jl:137-143).
+// Own construction on top of the type-3 NUFFT kernels (validated in tools/proto_hankel.py):
+//   J_nu(z) = sqrt(2/(pi z)) Re{ e^{i(z-chi)} sum_k i^k a_k(nu) z^-k },  z >= z0 = 24, K = 16 terms,
+// so for lags of level l (r in (r_hi/8^(l+1), r_hi/8^l]) the sources w >= om_l = z0 8^(l+1)/(2 pi r_hi)
+// contribute  sum_k i^k a_k (2 pi om_l r)^-(k+1/2)  T_k(r),  T_k(r) = sum_j c_j (w_j/om_l)^-(k+1/2)
+// e^{2 pi i w_j r}: K type-3 NUFFTs on the panel's fixed spread geometry (k_spread / rocFFT reused), and the
+// sources w < om_l (z < 8 z0 on the level's lag interval: a smooth function of r of bounded bandwidth)
+// are summed directly at 160 Chebyshev nodes of the interval and interpolated (Clenshaw) at the lags.
+
+// level of lag r: number of edges edge[1..L] that are >= r
+__device__ __forceinline__ int hk_level(const HankelPlan& hp, double r) {
+  int l = 0;
+  for (int q = 1; q <= hp.L; ++q) l += (r <= hp.edge[q]) ? 1 : 0;
+  return l;
+}
+
+// scaled, pre-phased strengths of the far sources of one level, all K terms: hk_src[k][rule-major j]
+__global__ void __launch_bounds__(256) k_hk_gen(DevConst dc, DevBuffers db, HankelPlan hp, int level, int slot) {
+  const DevState& s = db.state[slot];
+  if (s.done) return;
+  const PanelParams pp = s.pp;
+  const int64_t M = dc.M;
+  const int64_t jg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (jg >= 3 * M) return;
+  const int rule = jg < M ? 0 : 1;
+  const int64_t j = rule ? jg - M : jg;
+  const double2 cw = db.src[jg];  // (c_j, w_j) from k_gen
+  const double om = hp.om[level];
+  double2* out = db.hk_src + jg;
+  if (!(cw.y >= om)) {
+    for (int k = 0; k < kHkTerms; ++k) out[(int64_t)k * 3 * M] = make_double2(0.0, 0.0);
+    return;
+  }
+  const double P = dc.pos[pp.jacobi][rule][j];
+  const double u = (P - 0.5 * (double)dc.n1) * dc.delta;
+  const double2 ph = cis_turns_prod(pp.kappa, u);
+  const double q = om / cw.y;       // (w/om)^-1 in (0, 1]
+  double sc = cw.x * sqrt(q);       // c (w/om)^-(k+1/2), k = 0
+  for (int k = 0; k < kHkTerms; ++k) {
+    out[(int64_t)k * 3 * M] = make_double2(sc * ph.x, sc * ph.y);
+    sc *= q;
+  }
+}
+
+// near sums at the Chebyshev nodes: one workgroup per (level, rule, node)
+__global__ void __launch_bounds__(256) k_hk_near(DevConst dc, DevBuffers db, HankelPlan hp) {
+  __shared__ double sred[4];
+  const int node = blockIdx.x % kHkNodes;
+  const int rule = (blockIdx.x / kHkNodes) & 1;
+  const int level = blockIdx.x / (2 * kHkNodes);
+  const double hi_r = hp.edge[level], lo_r = hp.edge[level + 1];
+  const double half = 0.5 * (hi_r - lo_r), mid = 0.5 * (hi_r + lo_r);
+  const double r = mid + half * cospi((node + 0.5) / (double)kHkNodes);
+  const double om = hp.om[level];
+  const int64_t M = dc.M, cnt = rule ? 2 * M : M;
+  const double2* __restrict__ src = db.src + (rule ? M : 0);
+  const double tw = 2.0 * SK_PI * r;
+  double acc = 0.0;
+  for (int64_t j = threadIdx.x; j < cnt; j += blockDim.x) {
+    const double2 cw = src[j];
+    if (!(cw.y < om)) break;  // sources are sorted by w: the near set is a prefix
+    const double x = tw * cw.y;
+    const double jv = (hp.nu == 0) ? j0(x) : ((hp.nu == 1) ? j1(x) : jn(hp.nu, x));
+    acc = fma(cw.x, jv, acc);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) db.hk_nodes[((int64_t)level * 2 + rule) * kHkNodes + node] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+// node values -> Chebyshev coefficients (first-kind nodes): one workgroup per (level, rule)
+__global__ void __launch_bounds__(kHkNodes) k_hk_cheb(DevBuffers db) {
+  __shared__ double f[kHkNodes];
+  const double* in = db.hk_nodes + (int64_t)blockIdx.x * kHkNodes;
+  f[threadIdx.x] = in[threadIdx.x];
+  __syncthreads();
+  const int mth = threadIdx.x;
+  double acc = 0.0;
+  for (int sidx = 0; sidx < kHkNodes; ++sidx) acc = fma(f[sidx], cospi((double)mth * (sidx + 0.5) / (double)kHkNodes), acc);
+  db.hk_cheb[(int64_t)blockIdx.x * kHkNodes + mth] = acc * (mth == 0 ? 1.0 : 2.0) / (double)kHkNodes;
+}
+
+// lags of one level: far part from the K x 2 FFT grids, near part by Clenshaw, then the usual epilogue
+template <int W>
+__global__ void __launch_bounds__(256) k_hk_interp(DevConst dc, const EsConst* ec, DevBuffers db, HankelPlan hp, int level,
+                                                   int slot, long long n) {
+  __shared__ double smax[4];
+  __shared__ unsigned int shi[4];
+  __shared__ int sflag[2];
+  __shared__ double s_cheb[2][kHkNodes];
+  const DevState& s = db.state[slot];
+  if (s.done) return;
+  const PanelParams pp = s.pp;
+  const TailScalars tail = s.tail;
+  const int conf = s.conf, has_acc = s.has_acc, pc = s.pc, p_valid = s.p_valid, stack_len = s.stack_len;
+  const double T2 = dc.tol * s.k0abs * 0.5;
+  const long long ix1 = s.ix1, hi = s.hi;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((long long)blockIdx.x * blockDim.x >= hi) return;
+  if (threadIdx.x < 2) sflag[threadIdx.x] = 0;
+  for (int t = threadIdx.x; t < 2 * kHkNodes; t += blockDim.x)
+    s_cheb[t / kHkNodes][t % kHkNodes] = db.hk_cheb[((int64_t)level * 2 + t / kHkNodes) * kHkNodes + t % kHkNodes];
+  __syncthreads();
+  const bool inrange = (i >= ix1 && i < hi);
+  const double r = inrange ? db.xs[i] : 1.0;
+  const bool act = inrange && hk_level(hp, r) == level;
+  const int n2i = (int)dc.n2;
+  double emax = 0.0;
+  int n1f = 0, n2f = 0;
+  unsigned int unconv = 0u;
+  if (act) {
+    double I12[2] = {0.0, 0.0};
+    // ---- near part: Chebyshev interpolant of the level's lag interval
+    {
+      const double hi_r = hp.edge[level], lo_r = hp.edge[level + 1];
+      const double xx = (r - 0.5 * (hi_r + lo_r)) / (0.5 * (hi_r - lo_r));
+      for (int rule = 0; rule < 2; ++rule) {
+        double b1 = 0.0, b2 = 0.0;
+        for (int mth = kHkNodes - 1; mth >= 1; --mth) {
+          const double b0 = fma(2.0 * xx, b1, s_cheb[rule][mth] - b2);
+          b2 = b1;
+          b1 = b0;
+        }
+        I12[rule] = fma(xx, b1, s_cheb[rule][0] - b2);
+      }
+    }
+    // ---- far part (levels below L only)
+    if (level < hp.L) {
+      double v, y;
+      const int base = tap_base<W>(r, pp.r_hi, pp.inv_rc, pp.tau, n2i, v, y);
+      double wt[W];
+      es_weights<W>(ec->poly, y, wt);
+      const double zr = 2.0 * SK_PI * hp.om[level] * r;  // >= z0
+      const double izr = 1.0 / zr;
+      double sck = sqrt(izr);  // (2 pi om r)^-(k+1/2), k = 0
+      double a1r = 0, a1i = 0, a2r = 0, a2i = 0;  // sum_k i^k a_k sck H_k for both rules
+      for (int k = 0; k < kHkTerms; ++k) {
+        const double2* g1 = db.hk_fft + ((int64_t)k * 2) * n2i + base;
+        const double2* g2 = g1 + n2i;
+        double2 H1, H2;
+        tap_sums<W, true>(g1, g2, wt, H1, H2);
+        const double f = hp.a[k] * sck;
+        // multiply by i^k
+        double t1r, t1i, t2r, t2i;
+        switch (k & 3) {
+          case 0: t1r = H1.x; t1i = H1.y; t2r = H2.x; t2i = H2.y; break;
+          case 1: t1r = -H1.y; t1i = H1.x; t2r = -H2.y; t2i = H2.x; break;
+          case 2: t1r = -H1.x; t1i = -H1.y; t2r = -H2.x; t2i = -H2.y; break;
+          default: t1r = H1.y; t1i = -H1.x; t2r = H2.y; t2i = -H2.x; break;
+        }
+        a1r = fma(f, t1r, a1r); a1i = fma(f, t1i, a1i);
+        a2r = fma(f, t2r, a2r); a2i = fma(f, t2i, a2i);
+        sck *= izr;
+      }
+      double2 F1, F2;
+      interp_finish(dc, ec->cheb, r, pp.Cx, v, pp.theta_scale, make_double2(a1r, a1i), make_double2(a2r, a2i), F1, F2);
+      // Re{ e^{-i chi} F } sqrt(2/pi),  chi = (2 nu + 1) pi / 4
+      double sn, cs;
+      sincospi(0.25 * (2 * hp.nu + 1), &sn, &cs);
+      const double c0 = 0.79788456080286535588;  // sqrt(2/pi)
+      I12[0] += c0 * (cs * F1.x + sn * F1.y);
+      I12[1] += c0 * (cs * F2.x + sn * F2.y);
+    }
+    double scale = dc.c;  // src/quadrature.jl:250-255
+    if (dc.dim > 2) scale /= pow(r, dc.dim * 0.5 - 1.0);
+    const double I1 = I12[0] * scale, I2 = I12[1] * scale;
+    const double e = fabs(I2 - I1);
+    emax = e;
+    n1f = isnan(I1);
+    n2f = isnan(I2);
+    const int o = conf ^ 1;
+    const double Sk = (has_acc ? db.accK[conf][i] : 0.0) + I2, Se = (has_acc ? db.accE[conf][i] : 0.0) + e;
+    db.accK[o][i] = Sk;
+    db.accE[o][i] = Se;
+    const double pk = (p_valid ? db.P[pc][i] : 0.0) + I2;
+    double te2 = 0.0;
+    if (stack_len == 0) {
+      const int crit = tail.crit;
+      const double te = (crit == SK_CRIT_PANEL) ? 0.0 : trunc_est(tail, r, dc.dim);
+      const bool conv = (crit == SK_CRIT_PANEL || te < T2) && (crit == SK_CRIT_TAILS || fabs(pk) < T2);
+      unconv = conv ? 0u : (unsigned int)(i + 1);
+      te2 = 2.0 * te;
+    } else {
+      db.P[pc ^ 1][i] = pk;
+    }
+    db.ks[i] = Sk;
+    db.errs[i] = Se + te2;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    emax = fmax(emax, __shfl_xor(emax, off, 64));
+    const unsigned int o2 = __shfl_xor(unconv, off, 64);
+    unconv = o2 > unconv ? o2 : unconv;
+  }
+  if (__any(n1f) && (threadIdx.x & 63) == 0) atomicOr(&sflag[0], 1);
+  if (__any(n2f) && (threadIdx.x & 63) == 0) atomicOr(&sflag[1], 1);
+  if ((threadIdx.x & 63) == 0) {
+    smax[threadIdx.x >> 6] = emax;
+    shi[threadIdx.x >> 6] = unconv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double b = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    unsigned int h = shi[0];
+    for (int w2 = 1; w2 < 4; ++w2) h = shi[w2] > h ? shi[w2] : h;
+    Reductions& rd = db.red[slot];
+    const int a = blockIdx.x & 63;
+    if (b > 0.0) atomicMax(&rd.max_bits[a], (unsigned long long)__double_as_longlong(b));
+    if (h) atomicMax(&rd.hi[a], h);
+    const int f = sflag[0] | (sflag[1] << 1);
+    if (f) atomicOr(&rd.nan, f);
+  }
+}
+
 // ------------------------------------------------------------------ launchers
 
 static inline unsigned nblk(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
@@ -922,6 +1138,26 @@ void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, 
   const unsigned padblk = nblk(2 * (dc.n2 - dc.n1), kSpreadThreads);
   SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_spread<W>, dim3(tiles + padblk), dim3(kSpreadThreads), 0, st, dc, ec, db,
                                          slot));
+}
+void launch_hk_gen(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, int level, int slot, hipStream_t st) {
+  hipLaunchKernelGGL(k_hk_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, hp, level, slot);
+}
+void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st) {
+  // the fixed-geometry spread kernel, once per asymptotic term, on that term's strengths and grids
+  for (int k = 0; k < kHkTerms; ++k) {
+    DevBuffers d2 = db;
+    d2.src = db.hk_src + (int64_t)k * 3 * dc.M;
+    d2.fft = db.hk_fft + (int64_t)k * 2 * dc.n2;
+    launch_spread(dc, ec, d2, slot, st);
+  }
+}
+void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st) {
+  hipLaunchKernelGGL(k_hk_near, dim3((unsigned)((hp.L + 1) * 2 * kHkNodes)), dim3(256), 0, st, dc, db, hp);
+  hipLaunchKernelGGL(k_hk_cheb, dim3((unsigned)((hp.L + 1) * 2)), dim3(kHkNodes), 0, st, db);
+}
+void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HankelPlan& hp, int level, int slot,
+                      long long n, hipStream_t st) {
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_hk_interp<W>, dim3(nblk(n, 256)), dim3(256), 0, st, dc, ec, db, hp, level, slot, n));
 }
 void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st) {
   hipLaunchKernelGGL(k_bessel, dim3(nblk(n, 64)), dim3(256), 0, st, dc, db, slot, n);

@@ -40,6 +40,7 @@ struct SkConfigArgs
   k::Int64
   device::Cint
   nufft_width::Cint
+  hankel_min_lags::Cint
 end
 
 # void (*sk_sdf_batch_fn)(const double* w, double* out, size_t n, void* ctx)
@@ -79,7 +80,7 @@ function AdaptiveKernelConfig(f; df=nothing, dim=1, alpha=0.0, tol::Float64=1e-8
   crit = convergence_criteria == :both ? 0 : convergence_criteria == :panel ? 1 : 2
   args = SkConfigArgs(kind, prm(f), cb, ctx, C_NULL, C_NULL, dim, alpha, tol, derivative, logw, crit,
                       isnothing(tail) ? 0 : 1, isnothing(tail) ? 0.0 : Float64(tail),
-                      quadspec[1], quadspec[2], device, 0)
+                      quadspec[1], quadspec[2], device, 0, 0)
   h = Ref{Ptr{Cvoid}}(C_NULL)
   code = _check(ccall((:sk_config_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{SkConfigArgs}), h, args))
   code == 100 && @warn(_last_error())                       # src/adaptive.jl:38

@@ -250,3 +250,25 @@ def test_dim2_direct_bessel_path(sk, oracle, derivative):
         assert abs(sk.compute_k0(cfg) / k0 - 1) < 1e-7  # Bessel small-r limit factor, src/adaptive.jl:84-86
     with pytest.raises(sk.SpectralKernelsError):
         sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, 3), dim=3)
+
+
+@pytest.mark.parametrize("derivative,alpha", [(False, 0.0), (True, 0.0), (False, 1.5)])
+def test_dim2_fast_hankel_vs_oracle_and_direct(sk, oracle, derivative, alpha):
+    # nufht seam (src/quadrature.jl:137-143): level-split asymptotic NUFFTs + Chebyshev near field against
+    # the oracle's direct Bessel sums, and against the device's own direct kernel on a larger lag set
+    parms = (0.7, 1.3, 1.8)
+    kw = dict(dim=2, derivative=derivative, alpha=alpha, quadspec=(64, 8))
+    rs = np.concatenate([[0.0], np.sort(10.0 ** np.random.default_rng(5).uniform(-5, 0.1, 200))])
+    fast = sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, 2), hankel_min_lags=1, **kw)
+    ocfg = oracle.AdaptiveKernelConfig(oracle.SDF.matern(*parms, 2), **kw)
+    k0 = float(oracle.matern_cov(0.0, parms, d=2))
+    ks, errs = check_pair(sk, oracle, fast, ocfg, rs, k0, 1e-8)
+    slow = sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, 2), hankel_min_lags=-1, dim=2, derivative=derivative, alpha=alpha)
+    fast = sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, 2), hankel_min_lags=1, dim=2, derivative=derivative, alpha=alpha)
+    big = np.sort(np.random.default_rng(6).uniform(0.0, 1.4, 6000))
+    a, ea = sk.kernel_values(slow, big, k0=k0)
+    b, eb = sk.kernel_values(fast, big, k0=k0)
+    assert np.abs(a - b).max() / k0 <= 1e-10 and np.abs(ea - eb).max() / k0 <= 1e-10
+    assert fast.last_stats()["n_panels"] == slow.last_stats()["n_panels"]
+    if not derivative and alpha == 0.0:
+        assert np.abs(b - oracle.matern_cov(big, parms, d=2)).max() / k0 <= 10 * 1e-8
