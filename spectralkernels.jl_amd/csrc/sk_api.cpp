@@ -712,7 +712,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     void* p1 = nullptr; void* p2 = nullptr; void* p3 = nullptr; void* p4 = nullptr;
     if (hipMalloc(&p1, sizeof(double2) * (size_t)kHkTerms * 3 * cfg->M) != hipSuccess ||
         hipMalloc(&p2, sizeof(double2) * (size_t)kHkTerms * 2 * dc.n2) != hipSuccess ||
-        hipMalloc(&p3, sizeof(double) * (size_t)(kHkMaxLevels + 1) * 2 * kHkNodes) != hipSuccess ||
+        hipMalloc(&p3, sizeof(double) * (size_t)(kHkMaxLevels + 1) * 2 * kHkNodes * kHkSplit) != hipSuccess ||
         hipMalloc(&p4, sizeof(double) * (size_t)(kHkMaxLevels + 1) * 2 * kHkNodes) != hipSuccess) {
       sk_config_destroy(cfg);
       return fail(SK_EHIP, "hipMalloc(Hankel buffers) failed");

@@ -13,6 +13,7 @@ constexpr int kTraceCap = 4096;
 // nonuniform fast Hankel transform (dim >= 2): level-split asymptotic expansion
 constexpr int kHkTerms = 16;     // K terms of the Hankel asymptotic series (valid for z >= kHkZ0)
 constexpr int kHkNodes = 160;    // Chebyshev nodes of the near-field interpolant per lag level
+constexpr int kHkSplit = 16;     // workgroups sharing one near-field node sum
 constexpr int kHkMaxLevels = 12; // lag levels (ratio kHkBeta) incl. the innermost near-only one
 constexpr double kHkZ0 = 24.0;
 constexpr double kHkBeta = 8.0;
@@ -139,7 +140,7 @@ struct DevBuffers {
   // Hankel path (dim >= 2)
   double2* hk_src;          // kHkTerms x 3M scaled, pre-phased source strengths of the current level
   double2* hk_fft;          // kHkTerms x 2 x n2 complex grids of the current level
-  double* hk_nodes;         // (kHkMaxLevels+1) x 2 x kHkNodes near sums at the Chebyshev nodes
+  double* hk_nodes;         // (kHkMaxLevels+1) x 2 x kHkNodes x kHkSplit partial near sums at the Chebyshev nodes
   double* hk_cheb;          // same shape: Chebyshev coefficients
   unsigned long long* stamps;  // diagnostic builds only (SK_STAMPS): 8 words per k_spread workgroup
 };

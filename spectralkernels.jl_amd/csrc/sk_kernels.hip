@@ -371,8 +371,8 @@ __global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mod
       bad |= !(x >= 0.0);
       unsorted |= (i + 1 < n) && !(x < db.xs[i + 1]);
     }
-    if (__any(unsorted) && (threadIdx.x & 63) == 0) atomicOr(&db.flags[0], 1);
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&db.flags[1], 1);
+    if (__any(unsorted) && (threadIdx.x & 63) == 0 && !db.flags[0]) atomicOr(&db.flags[0], 1);
+    if (__any(bad) && (threadIdx.x & 63) == 0 && !db.flags[1]) atomicOr(&db.flags[1], 1);
   }
   if (sh.done) return;
   const PanelParams pp = sh.pp;
@@ -552,6 +552,121 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread(DevConst dc, const Es
     // (-1)^l centres the FFT output (index k + n2/2), so k_interp never wraps around
     const double dcv = ((l & 1) ? -1.0 : 1.0) * dc.deconv[l < 0 ? -l : l];
     db.fft[(int64_t)rule * n2 + (l < 0 ? l + n2 : l)] = make_double2(ar * dcv, ai * dcv);
+  }
+}
+
+// k_spread_multi: the same tile algorithm for the kHkTerms coefficient sets of the Hankel path in one
+// launch: the W kernel weights of a staged source are shared by all terms, only the strengths change.
+// Term k reads db.hk_src + k*3M and writes db.hk_fft + k*2*n2.
+template <int W>
+__global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, const EsConst* ec, DevBuffers db, int slot) {
+  constexpr int NT = kHkTerms;
+  __shared__ double s_w[kSpreadThreads * (W + 1)];
+  __shared__ double2 s_c[kSpreadThreads];
+  __shared__ int s_l0[kSpreadThreads];
+  __shared__ double2 s_red[kSpreadThreads];
+  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
+  const DevState& s = db.state[slot];
+  if (s.done) return;
+  const int variant = s.pp.jacobi;
+  const int64_t n1 = dc.n1, n2 = dc.n2;
+  const int ntiles = dc.ntiles[variant];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= ntiles) {
+    // zero padding of every term's FFT input: indices [n1 - n1/2, n2 - n1/2) of both rules
+    const int64_t npad = n2 - n1;
+    for (int64_t g = ((int64_t)blockIdx.x - ntiles) * kSpreadThreads + tid; g < (int64_t)NT * 2 * npad;
+         g += (int64_t)(gridDim.x - ntiles) * kSpreadThreads) {
+      const int64_t kr = g / npad, off = g - kr * npad;  // kr = k*2 + rule
+      db.hk_fft[kr * n2 + (n1 - n1 / 2) + off] = make_double2(0.0, 0.0);
+    }
+    return;
+  }
+  const int4 tl = dc.tiles[variant][blockIdx.x];
+  const int rule = (tl.x >> 30) & 1;
+  const int L0 = tl.x & 0x3fffffff;
+  const int ncell = tl.y;
+  const int jlo = tl.z, jhi = tl.w;
+  const int* __restrict__ cs = dc.cellstart[variant][rule];
+  const double* __restrict__ pos = dc.pos[variant][rule];
+  const double2* __restrict__ src = db.hk_src + (rule ? dc.M : 0);
+  const int64_t sstride = 3 * dc.M;
+  int c2 = 64;
+  while (c2 / 2 >= ncell && c2 > 1) c2 >>= 1;
+  const int spl = 64 / c2;
+  const int lane = tid & 63;
+  const int part = tid >> 6;
+  constexpr int NPART = kSpreadThreads / 64;
+  const int cell = lane / spl, sub = lane - cell * spl;
+  int J0 = 0, J1 = 0;
+  if (cell < ncell) {
+    const int L = L0 + cell;
+    J0 = cs[L - W / 2 < 0 ? 0 : L - W / 2];
+    J1 = cs[L + W / 2 > (int)n1 ? (int)n1 : L + W / 2];
+  }
+  stage_es_tables<W>(ec, s_poly, nullptr);
+  __syncthreads();
+  double ar[NT], ai[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) { ar[k] = 0.0; ai[k] = 0.0; }
+  for (int jb = jlo; jb < jhi; jb += kSpreadThreads) {
+    const int j = jb + tid;
+    const int nb = (jhi - jb) < kSpreadThreads ? (jhi - jb) : kSpreadThreads;
+    if (j < jhi) {
+      const double P = pos[j];
+      const double tcn = P - 0.5 * W;
+      const double l0d = ceil(tcn);
+      const double y = (l0d - tcn) - 0.5;
+      const double y2 = y * y;
+      s_l0[tid] = (int)l0d - L0;
+      double* wrow = &s_w[tid * (W + 1)];
+#pragma unroll
+      for (int qq = 0; qq < W / 2; ++qq) {
+        double E, O;
+        es_pair<W>(s_poly, qq, y2, E, O);
+        wrow[qq] = fma(y, O, E);
+        wrow[W - 1 - qq] = fma(-y, O, E);
+      }
+    }
+    const int j0 = (J0 > jb ? J0 : jb) - jb;
+    const int j1 = (J1 < jb + nb ? J1 : jb + nb) - jb;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      __syncthreads();  // weights staged (k == 0) / previous term's gather finished
+      if (j < jhi) s_c[tid] = src[(int64_t)k * sstride + j];
+      __syncthreads();
+      for (int jj = j0 + part * spl + sub; jj < j1; jj += NPART * spl) {
+        const int rel = cell - s_l0[jj];
+        if (rel >= 0 && rel < W) {
+          const double wv = s_w[jj * (W + 1) + rel];
+          const double2 c = s_c[jj];
+          ar[k] = fma(c.x, wv, ar[k]);
+          ai[k] = fma(c.y, wv, ai[k]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int64_t l = (int64_t)(L0 + cell) - n1 / 2;
+  const double dcv = (cell < ncell) ? ((l & 1) ? -1.0 : 1.0) * dc.deconv[l < 0 ? -l : l] : 0.0;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    double xr = ar[k], xi = ai[k];
+    for (int off = 1; off < spl; off <<= 1) {
+      xr += __shfl_xor(xr, off, 64);
+      xi += __shfl_xor(xi, off, 64);
+    }
+    __syncthreads();
+    if (sub == 0) s_red[part * 64 + cell] = make_double2(xr, xi);
+    __syncthreads();
+    if (part == 0 && sub == 0 && cell < ncell) {
+#pragma unroll
+      for (int pidx = 1; pidx < NPART; ++pidx) {
+        xr += s_red[pidx * 64 + cell].x;
+        xi += s_red[pidx * 64 + cell].y;
+      }
+      db.hk_fft[((int64_t)k * 2 + rule) * n2 + (l < 0 ? l + n2 : l)] = make_double2(xr * dcv, xi * dcv);
+    }
   }
 }
 
@@ -934,12 +1049,15 @@ __global__ void __launch_bounds__(256) k_hk_gen(DevConst dc, DevBuffers db, Hank
   }
 }
 
-// near sums at the Chebyshev nodes: one workgroup per (level, rule, node)
+// near sums at the Chebyshev nodes: kHkSplit workgroups per (level, rule, node), each a contiguous
+// share of the sorted sources; the partial sums are added in fixed order by k_hk_cheb (deterministic)
 __global__ void __launch_bounds__(256) k_hk_near(DevConst dc, DevBuffers db, HankelPlan hp) {
   __shared__ double sred[4];
-  const int node = blockIdx.x % kHkNodes;
-  const int rule = (blockIdx.x / kHkNodes) & 1;
-  const int level = blockIdx.x / (2 * kHkNodes);
+  const int split = blockIdx.x % kHkSplit;
+  const int bid = blockIdx.x / kHkSplit;
+  const int node = bid % kHkNodes;
+  const int rule = (bid / kHkNodes) & 1;
+  const int level = bid / (2 * kHkNodes);
   const double hi_r = hp.edge[level], lo_r = hp.edge[level + 1];
   const double half = 0.5 * (hi_r - lo_r), mid = 0.5 * (hi_r + lo_r);
   const double r = mid + half * cospi((node + 0.5) / (double)kHkNodes);
@@ -948,7 +1066,9 @@ __global__ void __launch_bounds__(256) k_hk_near(DevConst dc, DevBuffers db, Han
   const double2* __restrict__ src = db.src + (rule ? M : 0);
   const double tw = 2.0 * SK_PI * r;
   double acc = 0.0;
-  for (int64_t j = threadIdx.x; j < cnt; j += blockDim.x) {
+  const int64_t per = (cnt + kHkSplit - 1) / kHkSplit;
+  const int64_t jend = (split + 1) * per < cnt ? (split + 1) * per : cnt;
+  for (int64_t j = split * per + threadIdx.x; j < jend; j += blockDim.x) {
     const double2 cw = src[j];
     if (!(cw.y < om)) break;  // sources are sorted by w: the near set is a prefix
     const double x = tw * cw.y;
@@ -958,14 +1078,17 @@ __global__ void __launch_bounds__(256) k_hk_near(DevConst dc, DevBuffers db, Han
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) db.hk_nodes[((int64_t)level * 2 + rule) * kHkNodes + node] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  if (threadIdx.x == 0)
+    db.hk_nodes[(((int64_t)level * 2 + rule) * kHkNodes + node) * kHkSplit + split] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
 // node values -> Chebyshev coefficients (first-kind nodes): one workgroup per (level, rule)
 __global__ void __launch_bounds__(kHkNodes) k_hk_cheb(DevBuffers db) {
   __shared__ double f[kHkNodes];
-  const double* in = db.hk_nodes + (int64_t)blockIdx.x * kHkNodes;
-  f[threadIdx.x] = in[threadIdx.x];
+  const double* in = db.hk_nodes + ((int64_t)blockIdx.x * kHkNodes + threadIdx.x) * kHkSplit;
+  double fs = 0.0;
+  for (int q = 0; q < kHkSplit; ++q) fs += in[q];
+  f[threadIdx.x] = fs;
   __syncthreads();
   const int mth = threadIdx.x;
   double acc = 0.0;
@@ -1143,16 +1266,13 @@ void launch_hk_gen(const DevConst& dc, const DevBuffers& db, const HankelPlan& h
   hipLaunchKernelGGL(k_hk_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, hp, level, slot);
 }
 void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st) {
-  // the fixed-geometry spread kernel, once per asymptotic term, on that term's strengths and grids
-  for (int k = 0; k < kHkTerms; ++k) {
-    DevBuffers d2 = db;
-    d2.src = db.hk_src + (int64_t)k * 3 * dc.M;
-    d2.fft = db.hk_fft + (int64_t)k * 2 * dc.n2;
-    launch_spread(dc, ec, d2, slot, st);
-  }
+  // the fixed-geometry spread, all asymptotic terms in one launch
+  const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_spread_multi<W>, dim3(tiles + 512), dim3(kSpreadThreads), 0, st, dc, ec, db,
+                                         slot));
 }
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st) {
-  hipLaunchKernelGGL(k_hk_near, dim3((unsigned)((hp.L + 1) * 2 * kHkNodes)), dim3(256), 0, st, dc, db, hp);
+  hipLaunchKernelGGL(k_hk_near, dim3((unsigned)((hp.L + 1) * 2 * kHkNodes * kHkSplit)), dim3(256), 0, st, dc, db, hp);
   hipLaunchKernelGGL(k_hk_cheb, dim3((unsigned)((hp.L + 1) * 2)), dim3(kHkNodes), 0, st, db);
 }
 void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HankelPlan& hp, int level, int slot,
@@ -1283,8 +1403,9 @@ __global__ void k_check_sorted(const double* xs, long long n, int* flags) {
   const double x = xs[i];
   bool bad = !(x >= 0.0);  // negative or NaN
   bool unsorted = (i + 1 < n) && !(x < xs[i + 1]);
-  if (__any(unsorted) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
-  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+  // plain read first: on unsorted input every wave would otherwise hit the same address (180 us at 1e6 lags)
+  if (__any(unsorted) && (threadIdx.x & 63) == 0 && !flags[0]) atomicOr(&flags[0], 1);
+  if (__any(bad) && (threadIdx.x & 63) == 0 && !flags[1]) atomicOr(&flags[1], 1);
 }
 void launch_check_sorted(const double* xs, long long n, int* flags, hipStream_t st) {
   hipLaunchKernelGGL(k_check_sorted, dim3(nblk(n, 256)), dim3(256), 0, st, xs, n, flags);
