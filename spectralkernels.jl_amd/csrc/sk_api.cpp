@@ -259,12 +259,18 @@ static hipEvent_t ev_get(sk_config* cfg) {
   }
   return cfg->ev_pool[cfg->ev_used++];
 }
+// SK_DEBUG_SYNC=1: name every launch group on stderr and synchronise after it, so that an asynchronous
+// GPU fault can be attributed to a kernel (diagnostics only; serialises the pipeline).
+static const bool g_debug_sync = getenv("SK_DEBUG_SYNC") != nullptr;
+static const char* const k_names[SK_K_COUNT] = {"k_gen", "k_spread", "rocfft", "k_interp", "k_advance"};
+
 struct EvScope {
   sk_config* cfg;
   hipStream_t st;
   int kid;
   hipEvent_t a, b;
   EvScope(sk_config* c, hipStream_t s, int k) : cfg(c), st(s), kid(k) {
+    if (g_debug_sync) fprintf(stderr, "[sk] launch %s\n", k_names[kid]);
     if (cfg->profile) {
       a = ev_get(cfg);
       b = ev_get(cfg);
@@ -272,6 +278,10 @@ struct EvScope {
     }
   }
   ~EvScope() {
+    if (g_debug_sync) {
+      hipError_t e = hipStreamSynchronize(st);
+      fprintf(stderr, "[sk]   %s -> %s\n", k_names[kid], hipGetErrorString(e));
+    }
     if (cfg->profile) {
       (void)hipEventRecord(b, st);
       cfg->ev_recs.push_back({kid, a, b});
@@ -412,6 +422,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       { EvScope e(cfg, st, SK_K_ADVANCE); launch_advance(cfg->dc, db, mode, t, n, k0, ks0, seq, st); }
       int rc = wait_status(cfg, seq, st);
       if (rc) return rc;
+      if (cfg->h_status->flags[1] & 2) return fail(SK_EHIP, "internal error: inconsistent device state detected by a kernel guard");
       if (check_flags && (cfg->h_status->flags[0] || cfg->h_status->flags[1])) return SK_OK;
       if (hs->done) break;
       mode = SK_MODE_ASIS;
@@ -473,7 +484,12 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   // speculatively on it as is; the flags come back with the first status block (no extra sync).
   cfg->stats.n_unique = (int64_t)n;
   rc = run_core(cfg, d_xs, (long long)n, k0, ks0, d_vals, d_errs, (double*)cfg->ws, st, true);
-  const int unsorted = cfg->h_status->flags[0], invalid = cfg->h_status->flags[1];
+  const int unsorted = cfg->h_status->flags[0], invalid = cfg->h_status->flags[1] & 1;
+  if (cfg->h_status->flags[1] & 2) {
+    (void)hipStreamSynchronize(st);
+    (void)hipMemsetAsync(cfg->db.flags, 0, 2 * sizeof(int), st);
+    return fail(SK_EHIP, "internal error: inconsistent device state detected by a kernel guard");
+  }
   if (unsorted || invalid) {
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMemsetAsync(cfg->db.flags, 0, 2 * sizeof(int), st));

@@ -154,6 +154,16 @@ __device__ __forceinline__ double trunc_est(const TailScalars& t, double x, int 
   return fmin(t.t1, t.t2num * rcp);
 }
 
+// Defensive guard used by every kernel that indexes memory with state fields: a corrupted or stale
+// state must become a reported error (flags[1] bit 1), never an out-of-bounds access.
+__device__ __forceinline__ bool state_sane(const DevState& s, const DevBuffers& db, long long n) {
+  const bool ok = (s.n == n) && (s.ix1 == 0 || s.ix1 == 1) && (s.hi >= 0) && (s.hi <= n) && (s.conf == 0 || s.conf == 1) &&
+                  (s.pc == 0 || s.pc == 1) && (s.stack_len >= 0) && (s.stack_len <= kStackCap) &&
+                  (s.pp.jacobi == 0 || s.pp.jacobi == 1);
+  if (!ok && threadIdx.x == 0) atomicOr(&db.flags[1], 2);
+  return ok;
+}
+
 __device__ __forceinline__ bool step_accept(const DevState& s, double tol) {
   double maxe = __longlong_as_double((long long)s.max_err_bits);
   return !s.nan1 && (maxe < tol * s.k0abs);  // src/quadrature.jl:260
@@ -375,6 +385,7 @@ __global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mod
     if (__any(bad) && (threadIdx.x & 63) == 0 && !db.flags[1]) atomicOr(&db.flags[1], 1);
   }
   if (sh.done) return;
+  if (!state_sane(sh, db, n)) return;
   const PanelParams pp = sh.pp;
   const int64_t M = dc.M;
   const int64_t jg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -425,6 +436,7 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread(DevConst dc, const Es
   __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
   const DevState& s = db.state[slot];
   if (s.done) return;
+  if (!state_sane(s, db, s.n)) return;
   const int variant = s.pp.jacobi;
   const int64_t n1 = dc.n1, n2 = dc.n2;
   const int ntiles = dc.ntiles[variant];
@@ -568,6 +580,7 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
   __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
   const DevState& s = db.state[slot];
   if (s.done) return;
+  if (!state_sane(s, db, s.n)) return;
   const int variant = s.pp.jacobi;
   const int64_t n1 = dc.n1, n2 = dc.n2;
   const int ntiles = dc.ntiles[variant];
@@ -756,6 +769,7 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
   // read the needed state fields before any store so that the loads stay scalar
   const DevState& s = db.state[slot];
   if (s.done) return;
+  if (!state_sane(s, db, n)) return;
   const PanelParams pp = s.pp;
   const TailScalars tail = s.tail;
   const int conf = s.conf, has_acc = s.has_acc, pc = s.pc, p_valid = s.p_valid, stack_len = s.stack_len;
@@ -908,6 +922,7 @@ __global__ void __launch_bounds__(256) k_bessel(DevConst dc, DevBuffers db, int 
   __shared__ int sflag[2];
   const DevState& s = db.state[slot];
   if (s.done) return;
+  if (!state_sane(s, db, n)) return;
   const TailScalars tail = s.tail;
   const int conf = s.conf, has_acc = s.has_acc, pc = s.pc, p_valid = s.p_valid, stack_len = s.stack_len;
   const double T2 = dc.tol * s.k0abs * 0.5;
@@ -1025,6 +1040,7 @@ __device__ __forceinline__ int hk_level(const HankelPlan& hp, double r) {
 __global__ void __launch_bounds__(256) k_hk_gen(DevConst dc, DevBuffers db, HankelPlan hp, int level, int slot) {
   const DevState& s = db.state[slot];
   if (s.done) return;
+  if (!state_sane(s, db, s.n)) return;
   const PanelParams pp = s.pp;
   const int64_t M = dc.M;
   const int64_t jg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1106,6 +1122,7 @@ __global__ void __launch_bounds__(256) k_hk_interp(DevConst dc, const EsConst* e
   __shared__ double s_cheb[2][kHkNodes];
   const DevState& s = db.state[slot];
   if (s.done) return;
+  if (!state_sane(s, db, n)) return;
   const PanelParams pp = s.pp;
   const TailScalars tail = s.tail;
   const int conf = s.conf, has_acc = s.has_acc, pc = s.pc, p_valid = s.p_valid, stack_len = s.stack_len;
