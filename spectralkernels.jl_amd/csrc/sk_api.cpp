@@ -573,6 +573,15 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     if (hipGetDevice(&dev) != hipSuccess) return fail(SK_EHIP, "hipGetDevice failed");
   }
   HIPCHK(hipSetDevice(dev));
+  {
+    // eager module load on an idle device (see k_module_warmup)
+    static std::once_flag warm;
+    std::call_once(warm, [] {
+      (void)hipDeviceSynchronize();
+      launch_module_warmup(nullptr);
+      (void)hipDeviceSynchronize();
+    });
+  }
   sk_config* cfg = new sk_config();
   cfg->args = *args;
   cfg->m = m;
@@ -830,6 +839,10 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
   int rc = SK_OK;
   if (hipMemcpyAsync(d, xs, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
     rc = fail(SK_EHIP, "H2D copy failed");
+  if (getenv("SK_DBG_SYNC_H2D")) {
+    hipError_t e = hipStreamSynchronize(st);
+    fprintf(stderr, "[sk] H2D sync -> %s\n", hipGetErrorString(e));
+  }
   if (!rc) rc = sk_kernel_values_device(cfg, d, n, k0, param_derivative, d + n, d + 2 * n, st);
   if (!rc) {
     if (hipMemcpyAsync(vals_out, d + n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -146,7 +146,8 @@ struct DevBuffers {
 };
 
 // launchers (sk_kernels.hip)
-void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);  // callback SDFs only
+void launch_module_warmup(hipStream_t st);
+void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);  // callback SDFs, dim > 1
 void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                 hipStream_t st);
 void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st);

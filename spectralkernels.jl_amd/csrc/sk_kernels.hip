@@ -1249,6 +1249,15 @@ __global__ void __launch_bounds__(256) k_hk_interp(DevConst dc, const EsConst* e
 static inline unsigned nblk(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 
+// Forces the (lazy) load of this library's code object.  HIP loads a module at the first launch of
+// one of its kernels; on this stack that load raced with an in-flight pageable host-to-device copy
+// and ended in "Memory access fault" on near-null addresses (tools/diag/h2d.sh).  sk_config_create
+// therefore launches this empty kernel and synchronises while the device is idle.
+__global__ void k_module_warmup(int* p) {
+  if (p && threadIdx.x == 123456) *p = 0;
+}
+void launch_module_warmup(hipStream_t st) { hipLaunchKernelGGL(k_module_warmup, dim3(1), dim3(64), 0, st, (int*)nullptr); }
+
 void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st) {
   hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, st, dc, db, slot);
 }
