@@ -228,6 +228,7 @@ static const char* status_message(int code) {
       return "The sub-interval (a, b) has been split too many times (b - a < 1e-16). Exiting to avoid infinite splitting.";
     case SK_ENAN: return "NaN detected in panel integral...";
     case SK_ESTACK: return "splitting stack capacity (5000) exceeded";
+    case SK_EHIP: return "internal error: inconsistent device state detected by a kernel guard";
     default: return "device-side failure";
   }
 }

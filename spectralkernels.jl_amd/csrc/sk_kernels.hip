@@ -155,13 +155,14 @@ __device__ __forceinline__ double trunc_est(const TailScalars& t, double x, int 
 }
 
 // Defensive guard used by every kernel that indexes memory with state fields: a corrupted or stale
-// state must become a reported error (flags[1] bit 1), never an out-of-bounds access.
+// state must never become an out-of-bounds access.  Pure (no stores: a store ahead of the table
+// loads would turn k_interp's scalar loads into uniform vector loads, +17 us); step_state turns an
+// insane state into done = -SK_EHIP, which the host reports.
 __device__ __forceinline__ bool state_sane(const DevState& s, const DevBuffers& db, long long n) {
-  const bool ok = (s.n == n) && (s.ix1 == 0 || s.ix1 == 1) && (s.hi >= 0) && (s.hi <= n) && (s.conf == 0 || s.conf == 1) &&
-                  (s.pc == 0 || s.pc == 1) && (s.stack_len >= 0) && (s.stack_len <= kStackCap) &&
-                  (s.pp.jacobi == 0 || s.pp.jacobi == 1);
-  if (!ok && threadIdx.x == 0) atomicOr(&db.flags[1], 2);
-  return ok;
+  (void)db;
+  return (s.n == n) && (s.ix1 == 0 || s.ix1 == 1) && (s.hi >= 0) && (s.hi <= n) && (s.conf == 0 || s.conf == 1) &&
+         (s.pc == 0 || s.pc == 1) && (s.stack_len >= 0) && (s.stack_len <= kStackCap) &&
+         (s.pp.jacobi == 0 || s.pp.jacobi == 1);
 }
 
 __device__ __forceinline__ bool step_accept(const DevState& s, double tol) {
@@ -285,7 +286,8 @@ __device__ void step_state(DevState& sh, const DevConst& dc, const DevBuffers& d
       sh = db.state[(mode == SK_MODE_TRANSITION ? t - 1 : t) & 1];
       if (mode == SK_MODE_TRANSITION) transition(sh, dc, db, r_max, r_hi, r_nan, lead);
     }
-    if (lead && mode != SK_MODE_ASIS) db.state[t & 1] = sh;
+    if (!sh.done && !state_sane(sh, db, n)) sh.done = -SK_EHIP;
+    if (lead && (mode != SK_MODE_ASIS || sh.done == -SK_EHIP)) db.state[t & 1] = sh;
   }
   // reset the reduction slots that k_interp(t) will accumulate into (last read by k_gen(t-1))
   if (lead && threadIdx.x < 64) {
