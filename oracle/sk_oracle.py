@@ -34,7 +34,7 @@ class _Cfg(C.Structure):
                 ("m", C.c_long), ("k", C.c_long),
                 ("leg_no1", C.c_void_p), ("leg_wt1", C.c_void_p), ("leg_no2", C.c_void_p), ("leg_wt2", C.c_void_p),
                 ("jac_no1", C.c_void_p), ("jac_wt1", C.c_void_p), ("jac_no2", C.c_void_p), ("jac_wt2", C.c_void_p),
-                ("nthreads", C.c_int), ("use_nufft", C.c_int)]
+                ("nthreads", C.c_int), ("use_nufft", C.c_int), ("df", _SDF_FN)]
 
 
 class _Rec(C.Structure):
@@ -152,8 +152,13 @@ class AdaptiveKernelConfig:
         if self.f.kind == SDF_CALLBACK:
             fn = self.f.fn
             cb = _SDF_FN(lambda w, ctx: float(fn(w)))
-            self._keep = cb
             s.f = cb
+            self._keep = [cb]
+            if self.df is not None:
+                dfn = self.df
+                dcb = _SDF_FN(lambda w, ctx: float(dfn(w)))
+                self._keep.append(dcb)
+                s.df = dcb
         s.dim, s.alpha, s.tol = self.dim, self.alpha, self.tol
         s.derivative, s.logw = int(self.derivative), int(self.logw)
         s.criteria = CRITERIA[self.convergence_criteria]
@@ -341,6 +346,34 @@ def sing_matern_cov(t, p, parms, d=1, dps=50):
                 / mp.gamma(b + d_ / 2)
             out.append(float(o))
     return np.array(out)
+
+
+def sing_matern_cov_dalpha(t, alpha, parms, d=1, dps=50):
+    """d/d(alpha) of sing_matern_cov(t, -alpha, parms) -- the truth of the reference's "derivative in α"
+    test (test/matern_sdf.jl:69-85, ForwardDiff there; mpmath numerical differentiation here)."""
+    import mpmath as mp
+    out = []
+    with mp.workdps(dps):
+        for ti in np.atleast_1d(np.asarray(t, dtype=float)):
+            def g(a, ti=ti):
+                return _sing_matern_mp(mp.mpf(float(ti)) + mp.mpf("1e-30"), -a, parms, d)
+            out.append(float(mp.diff(g, mp.mpf(float(alpha)))))
+    return np.array(out)
+
+
+def _sing_matern_mp(tt, p_, parms, d):
+    import mpmath as mp
+    phi, a, b = [mp.mpf(float(v)) for v in parms]
+    d_ = mp.mpf(float(d))
+    pi = mp.pi
+    z = a ** 2 * pi ** 2 * tt ** 2
+    o = pi ** p_ * (a * tt) ** p_ * mp.gamma((d_ + p_) / 2) * mp.hyp1f2((d_ + p_) / 2, d_ / 2, (2 - 2 * b + p_) / 2, z) \
+        / (mp.gamma(d_ / 2) * mp.gamma((2 - 2 * b + p_) / 2))
+    o -= pi ** (2 * b) * (a * tt) ** (2 * b) * mp.gamma(b + d_ / 2) \
+        * mp.hyp1f2(b + d_ / 2, 1 + b - p_ / 2, b + d_ / 2 - p_ / 2, z) \
+        / (mp.gamma(1 + b - p_ / 2) * mp.gamma(b + d_ / 2 - p_ / 2))
+    o *= phi * a ** (-2 * b) * pi ** (1 + d_ / 2 - p_) * tt ** (-p_) * mp.csc(b * pi - (p_ * pi) / 2) / mp.gamma(b + d_ / 2)
+    return o
 
 
 def sing_matern_k0(alpha, parms, d=1):
