@@ -35,7 +35,7 @@ typedef enum {
   SK_ESTACK = 4,       /* splitting stack capacity 5000 exceeded (src/quadrature.jl:7-15) */
   SK_EHIP = 5,         /* HIP / rocFFT runtime failure */
   SK_ENODEVICE = 6,    /* no gfx950 device visible: the product path has no CPU fallback */
-  SK_EUNSUPPORTED = 7, /* option outside the implemented scope (logw, dim > 2) */
+  SK_EUNSUPPORTED = 7, /* option outside the implemented scope (logw with dim > 2, as in the reference; logw with derivative) */
   SK_WARN_QUADSPEC = 100 /* tol < 1e-12 shrank quadspec to (2^12, 1) (src/adaptive.jl:37-40); config is valid */
 } sk_status;
 
@@ -60,7 +60,7 @@ typedef struct {
   double sdf_params[8];
   sk_sdf_batch_fn f;       /* used iff sdf_kind == SK_SDF_CALLBACK */
   void* f_ctx;
-  sk_sdf_batch_fn df;      /* derivative of the SDF; only needed for logw (unsupported yet) */
+  sk_sdf_batch_fn df;      /* derivative of the SDF: callback SDFs with logw=1 (src/quadrature.jl:194) */
   void* df_ctx;
   int dim;                 /* 1 (cos/sin kernel); even dims: Bessel kernels (fast Hankel transform or direct sums) */
   double alpha;            /* |w|^-alpha singularity at the origin */

@@ -22,7 +22,7 @@ _LIB = None
 SDF_CALLBACK, SDF_MATERN, SDF_EXPONENTIAL, SDF_GAUSSIAN = 0, 1, 2, 3
 CRITERIA = {"both": 0, "panel": 1, "tails": 2}
 ERRORS = {2: "sub-interval split too many times (b - a < 1e-16)", 3: "NaN detected in panel integral",
-          4: "splitting stack overflow", 7: "unsupported option in oracle (logw)"}
+          4: "splitting stack overflow", 7: "singularity derivative not implemented in d > 2"}
 
 _SDF_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
 

@@ -69,9 +69,8 @@ def _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, t
     for i in range(8):
         a.sdf_params[i] = f.params[i] if i < len(f.params) else 0.0
     keep = None
-    if f.kind == L.SDF_CALLBACK:
-        fn = f.fn
 
+    def _wrap(fn):
         def _batch(wp, outp, n, ctx):
             w = np.ctypeslib.as_array(wp, shape=(n,))
             out = np.ctypeslib.as_array(outp, shape=(n,))
@@ -83,8 +82,14 @@ def _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, t
                 v = np.array([float(fn(float(x))) for x in w])
             out[:] = v
 
-        keep = L.SDF_BATCH_FN(_batch)
-        a.f = keep
+        return L.SDF_BATCH_FN(_batch)
+
+    if f.kind == L.SDF_CALLBACK:
+        keep = [_wrap(f.fn)]
+        a.f = keep[0]
+        if df is not None:  # derivative of the SDF, used by logw=True (src/quadrature.jl:194)
+            keep.append(_wrap(df.fn if isinstance(df, SDF) else df))
+            a.df = keep[1]
     a.dim, a.alpha, a.tol = int(dim), float(alpha), float(tol)
     a.derivative, a.logw = int(bool(derivative)), int(bool(logw))
     a.criteria = _CRIT[convergence_criteria]

@@ -58,7 +58,7 @@ struct sk_config {
   double p, c;
   int device;
   int warned;
-  SdfHost sdf;
+  SdfHost sdf, dsdf;
   // host rules
   std::vector<double> leg[4], jac[4];
   EsTables tab;
@@ -72,7 +72,7 @@ struct sk_config {
   rocfft_plan plan_hk = nullptr;   // batch 2*kHkTerms, Hankel path
   void* fft_work_hk = nullptr;
   rocfft_execution_info info_hk = nullptr;
-  double hk_a[kHkTerms];
+  double hk_a[kHkTerms], hk_a2[kHkTerms];  // a_k(nu) of the main order and of dim/2 (logw pass B)
   rocfft_execution_info info = nullptr;
   void* fft_work = nullptr;
   double* d_fvals = nullptr;
@@ -91,7 +91,7 @@ struct sk_config {
   sk_stats stats;
   std::vector<TraceRec> trace;
   // callback scratch
-  std::vector<double> h_nodes, h_fvals;
+  std::vector<double> h_nodes, h_fvals, h_fvals2, h_dfvals;
   // optional per-kernel event timing
   int profile = 0;
   std::vector<hipEvent_t> ev_pool;
@@ -318,7 +318,7 @@ static int wait_status(sk_config* cfg, unsigned int seq, hipStream_t st) {
 
 // core march on sorted unique lags already on the device (src/adaptive.jl:110-202)
 static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0, double ks0, double* d_ks, double* d_errs,
-                    double* d_scratch6n, hipStream_t st, bool check_flags) {
+                    double* d_scratch6n /* 10 n for logw */, hipStream_t st, bool check_flags) {
   DevBuffers& db = cfg->db;
   db.xs = d_uxs;
   db.ks = d_ks;
@@ -329,12 +329,16 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   db.accE[1] = db.accE[0] + n;
   db.P[0] = db.accE[1] + n;
   db.P[1] = db.P[0] + n;
+  db.lw_raw = db.P[1] + n;  // 4 n doubles, only allocated (and used) for logw configs
   db.fvals = cfg->d_fvals;
   const bool cb = (cfg->dc.sdf_kind == SK_SDF_CALLBACK);
+  const bool logw = cfg->dc.logw != 0;
   // dim >= 2: fast Hankel transform (host-driven per step: the level split depends on r_hi) or direct sums
   const int hk_min = cfg->args.hankel_min_lags == 0 ? 2048 : cfg->args.hankel_min_lags;
   const bool hankel = cfg->dc.dim > 1 && hk_min > 0 && n >= hk_min;
-  const bool host_step = cb || hankel;  // the host needs state_t before each step
+  // the host needs state_t before each step: callback SDFs (node values), Hankel (level split), logw (the first
+  // panel takes two passes and a boundary term, src/quadrature.jl:186-228)
+  const bool host_step = cb || hankel || logw;
   db.check_input = (check_flags && !host_step) ? 1 : 0;
   if (check_flags && host_step) launch_check_sorted(d_uxs, n, db.flags, st);  // k_gen never runs in INIT mode here
   sk_stats& stt = cfg->stats;
@@ -342,33 +346,51 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   int t = 0;             // step counter: step t evaluates the panel described by state_t
   int mode = SK_MODE_INIT;
   int R = host_step ? 1 : 2;
-  for (;;) {
-    if (host_step) {
-      // host closure: needs state_t (panel bounds) before the step can be generated
-      const unsigned int seq = ++cfg->seq;
-      launch_advance(cfg->dc, db, mode, t, n, k0, ks0, seq, st);
-      int rc = wait_status(cfg, seq, st);
-      if (rc) return rc;
-      if (check_flags && (cfg->h_status->flags[0] || cfg->h_status->flags[1])) return SK_OK;
-      if (hs->done) break;
-      if (cb) {
-        host_nodes(cfg, hs->pp, cfg->h_nodes);
-        cfg->h_fvals.resize(cfg->h_nodes.size());
-        cfg->sdf.batch(cfg->h_nodes.data(), cfg->h_fvals.data(), cfg->h_nodes.size());
-        HIPCHK(hipMemcpyAsync(cfg->d_fvals, cfg->h_fvals.data(), sizeof(double) * cfg->h_fvals.size(),
-                              hipMemcpyHostToDevice, st));
-        double fb = cfg->sdf(hs->b);
-        HIPCHK(hipMemcpyAsync(&db.state[t & 1].fb, &fb, sizeof(double), hipMemcpyHostToDevice, st));
+  const int nu_main = cfg->dc.derivative ? cfg->dc.dim / 2 : cfg->dc.dim / 2 - 1;  // src/quadrature.jl:176-180
+
+  // callback SDFs: integrand `g` at the nodes of the current (sub)panel, evaluated on the host
+  // (src/quadrature.jl:184-247) and uploaded for k_gen
+  auto upload_fvals = [&](int g, std::vector<double>& hv) -> int {
+    const std::vector<double>& w = cfg->h_nodes;
+    hv.resize(w.size());
+    cfg->sdf.batch(w.data(), hv.data(), w.size());
+    if (logw) {
+      if (g == SK_G_LOGA) {
+        cfg->h_dfvals.resize(w.size());
+        cfg->dsdf.batch(w.data(), cfg->h_dfvals.data(), w.size());
+        for (size_t q = 0; q < w.size(); ++q) hv[q] = hv[q] + w[q] * std::log(w[q]) * cfg->h_dfvals[q];
+      } else if (g == SK_G_LOGB) {
+        for (size_t q = 0; q < w.size(); ++q) hv[q] = w[q] * std::log(w[q]) * hv[q];
+      } else {
+        for (size_t q = 0; q < w.size(); ++q) hv[q] *= std::log(w[q]);
       }
-      launch_tail(cfg->dc, db, t & 1, st);
-      mode = SK_MODE_ASIS;
     }
-    if (hankel) {
-      // ---- one step of the Hankel path (see "nonuniform fast Hankel transform" in sk_kernels.hip)
+    HIPCHK(hipMemcpyAsync(cfg->d_fvals, hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice, st));
+    return SK_OK;
+  };
+
+  // one evaluation of the current (sub)panel with integrand g and Bessel order nu (dim > 1); raw != 0 stores
+  // the panel sums instead of running the epilogue
+  auto eval_pass = [&](int g, int nu, int raw, std::vector<double>& hv) -> int {
+    if (cb) {
+      int rc = upload_fvals(g, hv);
+      if (rc) return rc;
+    }
+    { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, g, st); }
+    if (cfg->dc.dim == 1) {
+      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->d_ec, db, t & 1, st); }
+      {
+        EvScope e(cfg, st, SK_K_FFT);
+        int rc = run_fft(cfg, st);
+        if (rc) return rc;
+      }
+      { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->d_ec, db, t & 1, n, raw, st); }
+    } else if (hankel) {
+      // ---- the Hankel path (see "nonuniform fast Hankel transform" in sk_kernels.hip)
       HankelPlan hp;
       std::memset(&hp, 0, sizeof(hp));
-      hp.nu = cfg->dc.derivative ? cfg->dc.dim / 2 : cfg->dc.dim / 2 - 1;
-      std::memcpy(hp.a, cfg->hk_a, sizeof(hp.a));
+      hp.nu = nu;
+      std::memcpy(hp.a, nu == nu_main ? cfg->hk_a : cfg->hk_a2, sizeof(hp.a));
       const double r_hi = hs->pp.r_hi, pb = hs->pp.pb;
       int L = 0;
       while (L < kHkMaxLevels - 1 && kHkZ0 * std::pow(kHkBeta, L + 1) / (2.0 * M_PI * r_hi) < pb) ++L;
@@ -379,7 +401,6 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       }
       hp.edge[0] = r_hi;
       hp.edge[L + 1] = 0.0;
-      { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, st); }
       launch_hk_near(cfg->dc, db, hp, st);
       for (int l = 0; l < L; ++l) {
         launch_hk_gen(cfg->dc, db, hp, l, t & 1, st);
@@ -390,29 +411,50 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
           void* in[1] = {db.hk_fft};
           FFTCHK(rocfft_execute(cfg->plan_hk, in, nullptr, cfg->info_hk));
         }
-        { EvScope e(cfg, st, SK_K_INTERP); launch_hk_interp(cfg->dc, cfg->d_ec, db, hp, l, t & 1, n, st); }
+        { EvScope e(cfg, st, SK_K_INTERP); launch_hk_interp(cfg->dc, cfg->d_ec, db, hp, l, t & 1, n, raw, st); }
       }
-      { EvScope e(cfg, st, SK_K_INTERP); launch_hk_interp(cfg->dc, cfg->d_ec, db, hp, L, t & 1, n, st); }
-      ++t;
-      mode = SK_MODE_TRANSITION;
-      stt.n_steps_launched++;
-      continue;
+      { EvScope e(cfg, st, SK_K_INTERP); launch_hk_interp(cfg->dc, cfg->d_ec, db, hp, L, t & 1, n, raw, st); }
+    } else {
+      // isotropic d-dimensional kernel, few lags: direct Bessel sums (src/quadrature.jl:145-160)
+      if (!host_step) launch_tail(cfg->dc, db, t & 1, st);
+      EvScope e(cfg, st, SK_K_INTERP);
+      launch_bessel(cfg->dc, db, t & 1, n, nu, raw, st);
+    }
+    return SK_OK;
+  };
+
+  for (;;) {
+    bool lw_first = false;
+    if (host_step) {
+      // host closure: needs state_t (panel bounds) before the step can be generated
+      const unsigned int seq = ++cfg->seq;
+      launch_advance(cfg->dc, db, mode, t, n, k0, ks0, seq, st);
+      int rc = wait_status(cfg, seq, st);
+      if (rc) return rc;
+      if (check_flags && (cfg->h_status->flags[0] || cfg->h_status->flags[1])) return SK_OK;
+      if (hs->done) break;
+      if (cb) {
+        host_nodes(cfg, hs->pp, cfg->h_nodes);
+        double fb = cfg->sdf(hs->b);
+        HIPCHK(hipMemcpyAsync(&db.state[t & 1].fb, &fb, sizeof(double), hipMemcpyHostToDevice, st));
+      }
+      launch_tail(cfg->dc, db, t & 1, st);
+      mode = SK_MODE_ASIS;
+      lw_first = logw && hs->pp.jacobi;  // _a == 0 && p != 0 (src/quadrature.jl:185-186)
     }
     for (int r = 0; r < R; ++r) {
-      { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, st); }
-      if (cfg->dc.dim == 1) {
-        { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->d_ec, db, t & 1, st); }
-        {
-          EvScope e(cfg, st, SK_K_FFT);
-          int rc = run_fft(cfg, st);
-          if (rc) return rc;
-        }
-        { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->d_ec, db, t & 1, n, st); }
-      } else {
-        // isotropic d-dimensional kernel, few lags: direct Bessel sums (src/quadrature.jl:145-160)
-        if (!cb) launch_tail(cfg->dc, db, t & 1, st);
+      if (lw_first) {
+        // I = (I0 - A + 2 pi x B)/(dim - alpha): A with the cos / J_{dim/2-1} kernel, B with sin / J_{dim/2}
+        int rc = eval_pass(SK_G_LOGA, cfg->dc.dim / 2 - 1, SK_RAW_A, cfg->h_fvals);
+        if (!rc) rc = eval_pass(SK_G_LOGB, cfg->dc.dim / 2, SK_RAW_B, cfg->h_fvals2);
+        if (rc) return rc;
+        const double pb = hs->pp.pb;
+        const double B0 = std::pow(pb, cfg->dc.dim / 2.0 + 1.0 - cfg->dc.alpha) * std::log(pb) * cfg->sdf(pb);  // :189
         EvScope e(cfg, st, SK_K_INTERP);
-        launch_bessel(cfg->dc, db, t & 1, n, st);
+        launch_lw_finish(cfg->dc, db, t & 1, n, B0, st);
+      } else {
+        int rc = eval_pass(SK_G_DEFAULT, nu_main, SK_RAW_NONE, cfg->h_fvals);
+        if (rc) return rc;
       }
       ++t;
       mode = SK_MODE_TRANSITION;
@@ -479,7 +521,8 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   if (n > (size_t)0x7fffffff) return fail(SK_EINVAL, "at most 2^31-1 lags per call");
   HIPCHK(hipSetDevice(cfg->device));
   const size_t a8 = ((n * 8 + 255) / 256) * 256;
-  int rc = ensure_ws(cfg, 6 * a8);
+  const size_t nscr = cfg->dc.logw ? 10 : 6;  // + 4 n raw panel sums of the logw passes
+  int rc = ensure_ws(cfg, nscr * a8);
   if (rc) return rc;
   // The input is checked for "strictly increasing, >= 0" on the device and the march starts
   // speculatively on it as is; the flags come back with the first status block (no extra sync).
@@ -502,14 +545,14 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   // src/adaptive.jl:99-120: unique + sort, then gather back
   std::memset(&cfg->stats, 0, sizeof(cfg->stats));
   const size_t tb = sort_unique_temp_bytes((long long)n);
-  rc = ensure_ws(cfg, 10 * a8 + tb + 256);
+  rc = ensure_ws(cfg, (4 + nscr) * a8 + tb + 256);
   if (rc) return rc;
   char* base = (char*)cfg->ws;
   double* uxs = (double*)base; base += a8;
   long long* inv = (long long*)base; base += a8;
   double* ks = (double*)base; base += a8;
   double* errs = (double*)base; base += a8;
-  double* scr = (double*)base; base += 6 * a8;
+  double* scr = (double*)base; base += nscr * a8;
   long long* d_nu = (long long*)base; base += 256;
   sort_unique(d_xs, (long long)n, uxs, inv, d_nu, base, tb, st);
   HIPCHK(hipMemcpyAsync(cfg->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -564,7 +607,15 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   int warned;
   int rc = validate(*args, m, k, warned);
   if (rc) return rc;
-  if (args->logw) return fail(SK_EUNSUPPORTED, "logw=true is not implemented on the HIP path yet");
+  if (args->logw) {
+    const double p0 = -args->alpha + (args->dim == 1 ? 0.0 : args->dim / 2.0) + (args->derivative ? 1.0 : 0.0);
+    if (p0 != 0.0 && args->dim > 2)  // src/quadrature.jl:221
+      return fail(SK_EUNSUPPORTED, "singularity derivative not implemented in d > 2");
+    if (args->derivative)  // the integration-by-parts panel (src/quadrature.jl:186-228) ignores `derivative`
+      return fail(SK_EUNSUPPORTED, "logw=true together with derivative=true is not supported");
+    if (p0 != 0.0 && args->sdf_kind == SK_SDF_CALLBACK && !args->df)
+      return fail(SK_EINVAL, "logw=true needs the SDF derivative df (src/quadrature.jl:194)");
+  }
   if (args->dim != 1 && (args->dim % 2 != 0))  // Int64(dim/2-1) is inexact for odd dim (src/quadrature.jl:138,179)
     return fail(SK_EINVAL, "dim must be 1 or even");
   if (!sk_device_available())
@@ -596,6 +647,9 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   std::memcpy(cfg->sdf.prm, args->sdf_params, sizeof(cfg->sdf.prm));
   cfg->sdf.f = args->f;
   cfg->sdf.ctx = args->f_ctx;
+  cfg->dsdf = cfg->sdf;  // only ever called for callback SDFs (the catalogue's derivative lives on the device)
+  cfg->dsdf.f = args->df;
+  cfg->dsdf.ctx = args->df_ctx;
   std::memset(&cfg->stats, 0, sizeof(cfg->stats));
   // rules (src/adaptive.jl:47-49)
   gauss_rule(m, 0.0, cfg->leg[0], cfg->leg[1]);
@@ -614,7 +668,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   DevConst& dc = cfg->dc;
   std::memset(&dc, 0, sizeof(dc));
   dc.m = m; dc.k = k; dc.M = cfg->M;
-  dc.dim = args->dim; dc.derivative = args->derivative; dc.crit0 = args->criteria; dc.has_tail = args->has_tail;
+  dc.dim = args->dim; dc.derivative = args->derivative; dc.crit0 = args->criteria; dc.has_tail = args->has_tail; dc.logw = args->logw;
   dc.alpha = args->alpha; dc.p = cfg->p; dc.c = cfg->c; dc.tol = args->tol; dc.tail = args->tail;
   dc.sdf_kind = args->sdf_kind;
   std::memcpy(dc.sdf_prm, args->sdf_params, sizeof(dc.sdf_prm));
@@ -749,6 +803,10 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     cfg->hk_a[0] = 1.0;
     for (int kq = 1; kq < kHkTerms; ++kq)
       cfg->hk_a[kq] = cfg->hk_a[kq - 1] * (4.0 * nu * nu - (2.0 * kq - 1.0) * (2.0 * kq - 1.0)) / (8.0 * kq);
+    const double nu2 = dc.dim / 2;
+    cfg->hk_a2[0] = 1.0;
+    for (int kq = 1; kq < kHkTerms; ++kq)
+      cfg->hk_a2[kq] = cfg->hk_a2[kq - 1] * (4.0 * nu2 * nu2 - (2.0 * kq - 1.0) * (2.0 * kq - 1.0)) / (8.0 * kq);
   }
   *out = cfg;
   if (warned) {

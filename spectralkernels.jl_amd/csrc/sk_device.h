@@ -33,7 +33,7 @@ struct HankelPlan {
 struct DevConst {
   // quadrature
   int64_t m, k, M;     // quadspec and M = m*k
-  int dim, derivative, crit0, has_tail;
+  int dim, derivative, crit0, has_tail, logw;
   double alpha, p, c, tol, tail;
   int sdf_kind;        // 0 = values supplied by host callback
   double sdf_prm[8];
@@ -100,6 +100,12 @@ struct DevState {
   int trace_len;
 };
 
+// integrand handed to the panel rule (src/quadrature.jl:184-247): S(w) [times w^p log(w) factors as the
+// panel requires], or the two integrands of the integration-by-parts formula for logw on [0, b]
+enum { SK_G_DEFAULT = 0, SK_G_LOGA = 1, SK_G_LOGB = 2 };
+// what an evaluation kernel does with the panel sums: the usual epilogue, or store them raw (logw passes A, B)
+enum { SK_RAW_NONE = 0, SK_RAW_A = 1, SK_RAW_B = 2 };
+
 // how k_gen / k_advance obtain the state of their step (see step_state in sk_kernels.hip)
 enum { SK_MODE_INIT = 0, SK_MODE_TRANSITION = 1, SK_MODE_ASIS = 2 };
 
@@ -142,22 +148,26 @@ struct DevBuffers {
   double2* hk_fft;          // kHkTerms x 2 x n2 complex grids of the current level
   double* hk_nodes;         // (kHkMaxLevels+1) x 2 x kHkNodes x kHkSplit partial near sums at the Chebyshev nodes
   double* hk_cheb;          // same shape: Chebyshev coefficients
+  // logw first-panel passes (src/quadrature.jl:186-228): raw panel sums A (rules 1, 2) then B (rules 1, 2), n each
+  double* lw_raw;
   unsigned long long* stamps;  // diagnostic builds only (SK_STAMPS): 8 words per k_spread workgroup
 };
 
 // launchers (sk_kernels.hip)
 void launch_module_warmup(hipStream_t st);
 void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);  // callback SDFs, dim > 1
-void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
+void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0, int g,
                 hipStream_t st);
 void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st);
-void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st);
+void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long n, int nu, int raw, hipStream_t st);
+// logw first panel: combine the raw sums of passes A and B with the boundary term (src/quadrature.jl:189,224-225)
+void launch_lw_finish(const DevConst& dc, const DevBuffers& db, int slot, long long n, double B0, hipStream_t st);
 void launch_hk_gen(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, int level, int slot, hipStream_t st);
 void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st);
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st);
 void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HankelPlan& hp, int level, int slot,
-                      long long n, hipStream_t st);
-void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, hipStream_t st);
+                      long long n, int raw, hipStream_t st);
+void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, int raw, hipStream_t st);
 void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                     unsigned int seq, hipStream_t st);
 

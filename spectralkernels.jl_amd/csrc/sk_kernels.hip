@@ -66,6 +66,19 @@ __device__ __forceinline__ double sdf_eval_dev(int kind, const double* prm, doub
   }
 }
 
+// dS/dw of the catalogue (the `df` keyword, src/adaptive.jl:24; only the logw first panel needs it)
+__device__ __forceinline__ double sdf_deriv_dev(int kind, const double* prm, double w) {
+  switch (kind) {
+    case SK_SDF_MATERN: {
+      const double e = -prm[2] - prm[3] * 0.5;
+      return prm[0] * e * 2.0 * w * pow(prm[1] * prm[1] + w * w, e - 1.0);
+    }
+    case SK_SDF_EXPONENTIAL: return -prm[0] * (w > 0.0 ? 1.0 : (w < 0.0 ? -1.0 : 0.0)) * exp(-prm[0] * fabs(w));
+    case SK_SDF_GAUSSIAN: return -2.0 * w / (prm[0] * prm[0]) * exp(-(w * w) / (prm[0] * prm[0]));
+    default: return __builtin_nan("");
+  }
+}
+
 // ------------------------------------------------------------------ scalar state logic
 
 __device__ void set_panel(DevState& s, const DevConst& dc, const double* xs, double pa, double pb) {
@@ -371,7 +384,7 @@ constexpr int kSpreadThreads = 256;
 // Gauss weight (updatequadbufs!, src/quadrature.jl:49-95) and the type-3 pre-phase; writes the
 // complex source strengths c'_j (rule 1: M entries, then rule 2: 2M entries).
 __global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mode, int t, long long n, double k0,
-                                             double ks0) {
+                                             double ks0, int g) {
   __shared__ DevState sh;
   step_state(sh, dc, db, mode, t, n, k0, ks0);
   if (mode == SK_MODE_INIT && db.check_input) {
@@ -412,7 +425,17 @@ __global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mod
     w = bmad2 * no[q] + bpad2;
     wq = wt[q] * bmad2 * (dc.p == 0.0 ? 1.0 : pow(w, dc.p));
   }
-  const double f = (dc.sdf_kind == SK_SDF_CALLBACK) ? db.fvals[jg] : sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, w);
+  double f;
+  if (dc.sdf_kind == SK_SDF_CALLBACK) {
+    f = db.fvals[jg];  // the host evaluated the whole integrand (log factors included)
+  } else {
+    f = sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, w);
+    if (dc.logw) {  // src/quadrature.jl:186-228, :243
+      if (g == SK_G_LOGA) f = fma(w * log(w), sdf_deriv_dev(dc.sdf_kind, dc.sdf_prm, w), f);
+      else if (g == SK_G_LOGB) f *= w * log(w);
+      else f *= log(w);
+    }
+  }
   const double cj = wq * f;
   if (dc.dim > 1) {  // Hankel path: k_bessel sums c_j J_nu(2 pi w_j r) directly, it needs the node itself
     db.src[jg] = make_double2(cj, w);
@@ -762,7 +785,7 @@ __device__ __forceinline__ void interp_finish(const DevConst& dc, const double* 
 // until then every later evaluation overwrites them.  Per workgroup: max |I2-I1|, NaN flags and the
 // highest lag failing the convergence predicate (src/adaptive.jl:183-198, :231-233), all
 // speculative on this panel being accepted -- k_advance decides.
-template <int W>
+template <int W, int RAW>
 __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, DevBuffers db, int slot, long long n) {
   __shared__ double smax[4];
   __shared__ unsigned int shi[4];
@@ -844,6 +867,13 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
 #else
     interp_finish(dc, ec->cheb, r, pp.Cx, v, pp.theta_scale, H1, H2, F1, F2);
 #endif
+    if constexpr (RAW != SK_RAW_NONE) {
+      // logw first panel (src/quadrature.jl:192-207): pass A keeps the cos sums, pass B the sin sums
+      double* out = db.lw_raw + (RAW == SK_RAW_A ? 0 : 2 * n);
+      out[i] = (RAW == SK_RAW_A) ? F1.x : F1.y;
+      out[n + i] = (RAW == SK_RAW_A) ? F2.x : F2.y;
+      return;
+    }
     const double scale = dc.c;  // src/quadrature.jl:250-255 (dim == 1)
     const double I1 = (dc.derivative ? F1.y : F1.x) * scale;
     const double I2 = (dc.derivative ? F2.y : F2.x) * scale;
@@ -876,6 +906,7 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
     db.errs[i] = Se + te2;
 #endif
   }
+  if constexpr (RAW != SK_RAW_NONE) return;
   // wave reductions by shuffles (same-address LDS atomics from 64 lanes serialise and were 10 us slower),
   // then one LDS slot per wave; NaNs are carried by the flags (fmax drops them)
   for (int off = 32; off > 0; off >>= 1) {
@@ -907,6 +938,119 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
   }
 }
 
+// ------------------------------------------------------------------ shared epilogue (dim >= 2, logw)
+
+// The part of an evaluation that follows the panel sums I1 (m rule) and I2 (2m rule) of one lag --
+// the same statements as at the end of k_interp, which keeps its own hand-scheduled copy.
+struct EpiState {
+  int conf, has_acc, pc, p_valid, stack_len;
+  double T2;
+  TailScalars tail;
+};
+__device__ __forceinline__ EpiState epi_load(const DevState& s, const DevConst& dc) {
+  EpiState e;
+  e.conf = s.conf; e.has_acc = s.has_acc; e.pc = s.pc; e.p_valid = s.p_valid; e.stack_len = s.stack_len;
+  e.T2 = dc.tol * s.k0abs * 0.5;
+  e.tail = s.tail;
+  return e;
+}
+__device__ __forceinline__ void lag_epilogue(const DevConst& dc, const DevBuffers& db, const EpiState& es, long long i,
+                                             double r, double I1, double I2, double& emax, int& n1f, int& n2f,
+                                             unsigned int& unconv) {
+  const double e = fabs(I2 - I1);
+  emax = e;
+  n1f = isnan(I1);
+  n2f = isnan(I2);
+  const int o = es.conf ^ 1;
+  const double Sk = (es.has_acc ? db.accK[es.conf][i] : 0.0) + I2, Se = (es.has_acc ? db.accE[es.conf][i] : 0.0) + e;
+  db.accK[o][i] = Sk;
+  db.accE[o][i] = Se;
+  const double pk = (es.p_valid ? db.P[es.pc][i] : 0.0) + I2;
+  double te2 = 0.0;
+  if (es.stack_len == 0) {
+    const int crit = es.tail.crit;
+    const double te = (crit == SK_CRIT_PANEL) ? 0.0 : trunc_est(es.tail, r, dc.dim);
+    const bool conv = (crit == SK_CRIT_PANEL || te < es.T2) && (crit == SK_CRIT_TAILS || fabs(pk) < es.T2);
+    unconv = conv ? 0u : (unsigned int)(i + 1);
+    te2 = 2.0 * te;
+  } else {
+    db.P[es.pc ^ 1][i] = pk;
+  }
+  db.ks[i] = Sk;
+  db.errs[i] = Se + te2;
+}
+// workgroup (256 threads) reduction of the per-lag results into the 64 spread slots of this step
+__device__ __forceinline__ void block_reduce(const DevBuffers& db, int slot, double emax, int n1f, int n2f,
+                                             unsigned int unconv) {
+  __shared__ double smax[4];
+  __shared__ unsigned int shi[4];
+  __shared__ int sflag[4][2];
+  for (int off = 32; off > 0; off >>= 1) {
+    emax = fmax(emax, __shfl_xor(emax, off, 64));
+    const unsigned int o2 = __shfl_xor(unconv, off, 64);
+    unconv = o2 > unconv ? o2 : unconv;
+  }
+  const int a1 = __any(n1f), a2 = __any(n2f);
+  if ((threadIdx.x & 63) == 0) {
+    smax[threadIdx.x >> 6] = emax;
+    shi[threadIdx.x >> 6] = unconv;
+    sflag[threadIdx.x >> 6][0] = a1;
+    sflag[threadIdx.x >> 6][1] = a2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double b = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    unsigned int h = shi[0];
+    int f = 0;
+    for (int w2 = 0; w2 < 4; ++w2) {
+      h = shi[w2] > h ? shi[w2] : h;
+      f |= (sflag[w2][0] ? 1 : 0) | (sflag[w2][1] ? 2 : 0);
+    }
+    Reductions& rd = db.red[slot];
+    const int a = blockIdx.x & 63;
+    if (b > 0.0) atomicMax(&rd.max_bits[a], (unsigned long long)__double_as_longlong(b));
+    if (h) atomicMax(&rd.hi[a], h);
+    if (f) atomicOr(&rd.nan, f);
+  }
+}
+
+// logw on [0, b] (src/quadrature.jl:186-228): I = (I0 - A + 2 pi x B) / (dim - alpha) with the boundary term
+// I0 = b^(dim/2+1-alpha) log(b) f(b) J_{dim/2-1}(2 pi b x) (:189; B0 = everything but the Bessel factor, from
+// the host) and the raw sums A, B of the two passes; then the usual epilogue.
+__global__ void __launch_bounds__(256) k_lw_finish(DevConst dc, DevBuffers db, int slot, long long n, double B0) {
+  const DevState& s = db.state[slot];
+  if (s.done) return;
+  if (!state_sane(s, db, n)) return;
+  const EpiState es = epi_load(s, dc);
+  const double pb = s.pp.pb;
+  const long long ix1 = s.ix1, hi = s.hi;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((long long)blockIdx.x * blockDim.x >= hi) return;
+  const bool act = (i >= ix1 && i < hi);
+  double emax = 0.0;
+  int n1f = 0, n2f = 0;
+  unsigned int unconv = 0u;
+  if (act) {
+    const double r = db.xs[i];
+    const double z = 2.0 * SK_PI * pb * r;
+    double bj;
+    if (dc.dim == 1) {
+      // besselj(-1/2, z) = sqrt(2/(pi z)) cos z, as the reference evaluates :189 for dim = 1
+      bj = sqrt(2.0 / (SK_PI * z)) * cis_turns_prod(pb, r).x;
+    } else {
+      bj = j0(z);
+    }
+    const double I0 = B0 * bj;
+    const double A1 = db.lw_raw[i], A2 = db.lw_raw[n + i], B1 = db.lw_raw[2 * n + i], B2 = db.lw_raw[3 * n + i];
+    const double den = (double)dc.dim - dc.alpha;
+    const double tw = 2.0 * SK_PI * r;
+    const double I1 = (I0 - A1 + tw * B1) / den * dc.c;  // :224-225, :250-255 (dim <= 2: no x^(dim/2-1) factor)
+    const double I2 = (I0 - A2 + tw * B2) / den * dc.c;
+    lag_epilogue(dc, db, es, i, r, I1, I2, emax, n1f, n2f, unconv);
+  }
+  block_reduce(db, slot, emax, n1f, n2f, unconv);
+}
+
 // ------------------------------------------------------------------ k_bessel (dim >= 2)
 
 // Isotropic d-dimensional kernels (src/quadrature.jl:137-161, :176-180, :250-255): the panel sums are
@@ -915,19 +1059,14 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
 // this first HIP version is the reference's own direct branch (:145-160) -- exact, O(N M), with the
 // node/coefficient tiles staged in LDS.  Everything else (march, acceptance, optimistic outputs)
 // is shared with the dim = 1 path.  Workgroup = 64 lags x 4 source partitions.
-__global__ void __launch_bounds__(256) k_bessel(DevConst dc, DevBuffers db, int slot, long long n) {
+__global__ void __launch_bounds__(256) k_bessel(DevConst dc, DevBuffers db, int slot, long long n, int nu, int raw) {
   constexpr int TS = 512;  // sources per LDS tile
   __shared__ double2 s_src[TS];
   __shared__ double s_part[2][4][64];
-  __shared__ double smax[4];
-  __shared__ unsigned int shi[4];
-  __shared__ int sflag[2];
   const DevState& s = db.state[slot];
   if (s.done) return;
   if (!state_sane(s, db, n)) return;
-  const TailScalars tail = s.tail;
-  const int conf = s.conf, has_acc = s.has_acc, pc = s.pc, p_valid = s.p_valid, stack_len = s.stack_len;
-  const double T2 = dc.tol * s.k0abs * 0.5;
+  const EpiState es = epi_load(s, dc);
   const long long ix1 = s.ix1, hi = s.hi;
   if ((long long)blockIdx.x * 64 >= hi) return;
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -935,8 +1074,6 @@ __global__ void __launch_bounds__(256) k_bessel(DevConst dc, DevBuffers db, int 
   const bool act = (i >= ix1 && i < hi);
   const double r = act ? db.xs[i] : 1.0;
   const double tw = 2.0 * SK_PI * r;
-  const int nu = dc.derivative ? dc.dim / 2 : dc.dim / 2 - 1;  // src/quadrature.jl:179
-  if (threadIdx.x < 2) sflag[threadIdx.x] = 0;
   double acc[2] = {0.0, 0.0};
   const int64_t M = dc.M;
   for (int rule = 0; rule < 2; ++rule) {
@@ -970,54 +1107,18 @@ __global__ void __launch_bounds__(256) k_bessel(DevConst dc, DevBuffers db, int 
       s1 += s_part[0][q][lane];
       s2 += s_part[1][q][lane];
     }
-    double scale = dc.c;  // src/quadrature.jl:250-255
-    if (dc.dim > 2) scale /= pow(r, dc.dim * 0.5 - 1.0);
-    const double I1 = s1 * scale, I2 = s2 * scale;
-    const double e = fabs(I2 - I1);
-    emax = e;
-    n1f = isnan(I1);
-    n2f = isnan(I2);
-    const int o = conf ^ 1;
-    const double Sk = (has_acc ? db.accK[conf][i] : 0.0) + I2, Se = (has_acc ? db.accE[conf][i] : 0.0) + e;
-    db.accK[o][i] = Sk;
-    db.accE[o][i] = Se;
-    const double pk = (p_valid ? db.P[pc][i] : 0.0) + I2;
-    double te2 = 0.0;
-    if (stack_len == 0) {
-      const int crit = tail.crit;
-      const double te = (crit == SK_CRIT_PANEL) ? 0.0 : trunc_est(tail, r, dc.dim);
-      const bool conv = (crit == SK_CRIT_PANEL || te < T2) && (crit == SK_CRIT_TAILS || fabs(pk) < T2);
-      unconv = conv ? 0u : (unsigned int)(i + 1);
-      te2 = 2.0 * te;
+    if (raw != SK_RAW_NONE) {  // logw passes (src/quadrature.jl:208-219)
+      double* out = db.lw_raw + (raw == SK_RAW_A ? 0 : 2 * n);
+      out[i] = s1;
+      out[n + i] = s2;
     } else {
-      db.P[pc ^ 1][i] = pk;
+      double scale = dc.c;  // src/quadrature.jl:250-255
+      if (dc.dim > 2) scale /= pow(r, dc.dim * 0.5 - 1.0);
+      lag_epilogue(dc, db, es, i, r, s1 * scale, s2 * scale, emax, n1f, n2f, unconv);
     }
-    db.ks[i] = Sk;
-    db.errs[i] = Se + te2;
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    emax = fmax(emax, __shfl_xor(emax, off, 64));
-    const unsigned int o2 = __shfl_xor(unconv, off, 64);
-    unconv = o2 > unconv ? o2 : unconv;
-  }
-  if (__any(n1f) && lane == 0) atomicOr(&sflag[0], 1);
-  if (__any(n2f) && lane == 0) atomicOr(&sflag[1], 1);
-  if (lane == 0) {
-    smax[part] = emax;
-    shi[part] = unconv;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double b = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
-    unsigned int h = shi[0];
-    for (int w2 = 1; w2 < 4; ++w2) h = shi[w2] > h ? shi[w2] : h;
-    Reductions& rd = db.red[slot];
-    const int a = blockIdx.x & 63;
-    if (b > 0.0) atomicMax(&rd.max_bits[a], (unsigned long long)__double_as_longlong(b));
-    if (h) atomicMax(&rd.hi[a], h);
-    const int f = sflag[0] | (sflag[1] << 1);
-    if (f) atomicOr(&rd.nan, f);
-  }
+  if (raw != SK_RAW_NONE) return;
+  block_reduce(db, slot, emax, n1f, n2f, unconv);
 }
 
 // ------------------------------------------------------------------ nonuniform fast Hankel transform
@@ -1117,22 +1218,16 @@ __global__ void __launch_bounds__(kHkNodes) k_hk_cheb(DevBuffers db) {
 // lags of one level: far part from the K x 2 FFT grids, near part by Clenshaw, then the usual epilogue
 template <int W>
 __global__ void __launch_bounds__(256) k_hk_interp(DevConst dc, const EsConst* ec, DevBuffers db, HankelPlan hp, int level,
-                                                   int slot, long long n) {
-  __shared__ double smax[4];
-  __shared__ unsigned int shi[4];
-  __shared__ int sflag[2];
+                                                   int slot, long long n, int raw) {
   __shared__ double s_cheb[2][kHkNodes];
   const DevState& s = db.state[slot];
   if (s.done) return;
   if (!state_sane(s, db, n)) return;
   const PanelParams pp = s.pp;
-  const TailScalars tail = s.tail;
-  const int conf = s.conf, has_acc = s.has_acc, pc = s.pc, p_valid = s.p_valid, stack_len = s.stack_len;
-  const double T2 = dc.tol * s.k0abs * 0.5;
+  const EpiState es = epi_load(s, dc);
   const long long ix1 = s.ix1, hi = s.hi;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if ((long long)blockIdx.x * blockDim.x >= hi) return;
-  if (threadIdx.x < 2) sflag[threadIdx.x] = 0;
   for (int t = threadIdx.x; t < 2 * kHkNodes; t += blockDim.x)
     s_cheb[t / kHkNodes][t % kHkNodes] = db.hk_cheb[((int64_t)level * 2 + t / kHkNodes) * kHkNodes + t % kHkNodes];
   __syncthreads();
@@ -1196,54 +1291,18 @@ __global__ void __launch_bounds__(256) k_hk_interp(DevConst dc, const EsConst* e
       I12[0] += c0 * (cs * F1.x + sn * F1.y);
       I12[1] += c0 * (cs * F2.x + sn * F2.y);
     }
-    double scale = dc.c;  // src/quadrature.jl:250-255
-    if (dc.dim > 2) scale /= pow(r, dc.dim * 0.5 - 1.0);
-    const double I1 = I12[0] * scale, I2 = I12[1] * scale;
-    const double e = fabs(I2 - I1);
-    emax = e;
-    n1f = isnan(I1);
-    n2f = isnan(I2);
-    const int o = conf ^ 1;
-    const double Sk = (has_acc ? db.accK[conf][i] : 0.0) + I2, Se = (has_acc ? db.accE[conf][i] : 0.0) + e;
-    db.accK[o][i] = Sk;
-    db.accE[o][i] = Se;
-    const double pk = (p_valid ? db.P[pc][i] : 0.0) + I2;
-    double te2 = 0.0;
-    if (stack_len == 0) {
-      const int crit = tail.crit;
-      const double te = (crit == SK_CRIT_PANEL) ? 0.0 : trunc_est(tail, r, dc.dim);
-      const bool conv = (crit == SK_CRIT_PANEL || te < T2) && (crit == SK_CRIT_TAILS || fabs(pk) < T2);
-      unconv = conv ? 0u : (unsigned int)(i + 1);
-      te2 = 2.0 * te;
+    if (raw != SK_RAW_NONE) {  // logw passes (src/quadrature.jl:208-219)
+      double* out = db.lw_raw + (raw == SK_RAW_A ? 0 : 2 * n);
+      out[i] = I12[0];
+      out[n + i] = I12[1];
     } else {
-      db.P[pc ^ 1][i] = pk;
+      double scale = dc.c;  // src/quadrature.jl:250-255
+      if (dc.dim > 2) scale /= pow(r, dc.dim * 0.5 - 1.0);
+      lag_epilogue(dc, db, es, i, r, I12[0] * scale, I12[1] * scale, emax, n1f, n2f, unconv);
     }
-    db.ks[i] = Sk;
-    db.errs[i] = Se + te2;
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    emax = fmax(emax, __shfl_xor(emax, off, 64));
-    const unsigned int o2 = __shfl_xor(unconv, off, 64);
-    unconv = o2 > unconv ? o2 : unconv;
-  }
-  if (__any(n1f) && (threadIdx.x & 63) == 0) atomicOr(&sflag[0], 1);
-  if (__any(n2f) && (threadIdx.x & 63) == 0) atomicOr(&sflag[1], 1);
-  if ((threadIdx.x & 63) == 0) {
-    smax[threadIdx.x >> 6] = emax;
-    shi[threadIdx.x >> 6] = unconv;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double b = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
-    unsigned int h = shi[0];
-    for (int w2 = 1; w2 < 4; ++w2) h = shi[w2] > h ? shi[w2] : h;
-    Reductions& rd = db.red[slot];
-    const int a = blockIdx.x & 63;
-    if (b > 0.0) atomicMax(&rd.max_bits[a], (unsigned long long)__double_as_longlong(b));
-    if (h) atomicMax(&rd.hi[a], h);
-    const int f = sflag[0] | (sflag[1] << 1);
-    if (f) atomicOr(&rd.nan, f);
-  }
+  if (raw != SK_RAW_NONE) return;
+  block_reduce(db, slot, emax, n1f, n2f, unconv);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -1279,9 +1338,9 @@ void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, l
     default: { constexpr int W = 16; CALL; } break; \
   }
 
-void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
+void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0, int g,
                 hipStream_t st) {
-  hipLaunchKernelGGL(k_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, mode, t, n, k0, ks0);
+  hipLaunchKernelGGL(k_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, mode, t, n, k0, ks0, g);
 }
 void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st) {
   // both variants have their own work list; launch for the longer one (extra blocks zero-pad or idle)
@@ -1304,15 +1363,24 @@ void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& 
   hipLaunchKernelGGL(k_hk_cheb, dim3((unsigned)((hp.L + 1) * 2)), dim3(kHkNodes), 0, st, db);
 }
 void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HankelPlan& hp, int level, int slot,
-                      long long n, hipStream_t st) {
-  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_hk_interp<W>, dim3(nblk(n, 256)), dim3(256), 0, st, dc, ec, db, hp, level, slot, n));
+                      long long n, int raw, hipStream_t st) {
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_hk_interp<W>, dim3(nblk(n, 256)), dim3(256), 0, st, dc, ec, db, hp, level, slot, n, raw));
 }
-void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long n, hipStream_t st) {
-  hipLaunchKernelGGL(k_bessel, dim3(nblk(n, 64)), dim3(256), 0, st, dc, db, slot, n);
+void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long n, int nu, int raw, hipStream_t st) {
+  hipLaunchKernelGGL(k_bessel, dim3(nblk(n, 64)), dim3(256), 0, st, dc, db, slot, n, nu, raw);
 }
-void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, hipStream_t st) {
+void launch_lw_finish(const DevConst& dc, const DevBuffers& db, int slot, long long n, double B0, hipStream_t st) {
+  hipLaunchKernelGGL(k_lw_finish, dim3(nblk(n, 256)), dim3(256), 0, st, dc, db, slot, n, B0);
+}
+void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, int raw, hipStream_t st) {
   const unsigned g = nblk(n, 256);
-  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_interp<W>, dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
+  if (raw == SK_RAW_A) {
+    SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp<W, SK_RAW_A>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
+  } else if (raw == SK_RAW_B) {
+    SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp<W, SK_RAW_B>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
+  } else {
+    SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp<W, SK_RAW_NONE>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
+  }
 }
 
 // ------------------------------------------------------------------ seam kernels (sk_panel_sums)

@@ -55,7 +55,7 @@ end
 mutable struct AdaptiveKernelConfig{S}
   f::S
   handle::Ptr{Cvoid}
-  fref::Base.RefValue{Any}      # keeps the closure alive for the callback
+  fref::Tuple{Base.RefValue{Any},Base.RefValue{Any}}  # keeps the closures (f, df) alive for the callbacks
   dim::Int64; alpha::Float64; tol::Float64; derivative::Bool; logw::Bool
   convergence_criteria::Symbol; tail::Union{Float64,Nothing}; quadspec::Tuple{Int64,Int64}
 end
@@ -77,8 +77,12 @@ function AdaptiveKernelConfig(f; df=nothing, dim=1, alpha=0.0, tol::Float64=1e-8
   fref = Ref{Any}(f)
   cb   = kind == 0 ? @cfunction(_sdf_batch, Cvoid, (Ptr{Cdouble}, Ptr{Cdouble}, Csize_t, Ptr{Cvoid})) : C_NULL
   ctx  = kind == 0 ? pointer_from_objref(fref) : C_NULL
+  # df: only read for callback SDFs with logw=true (src/quadrature.jl:194); catalogue SDFs differentiate on the device
+  dfref = Ref{Any}(df)
+  dcb   = (kind == 0 && !isnothing(df)) ? cb : C_NULL
+  dctx  = (kind == 0 && !isnothing(df)) ? pointer_from_objref(dfref) : C_NULL
   crit = convergence_criteria == :both ? 0 : convergence_criteria == :panel ? 1 : 2
-  args = SkConfigArgs(kind, prm(f), cb, ctx, C_NULL, C_NULL, dim, alpha, tol, derivative, logw, crit,
+  args = SkConfigArgs(kind, prm(f), cb, ctx, dcb, dctx, dim, alpha, tol, derivative, logw, crit,
                       isnothing(tail) ? 0 : 1, isnothing(tail) ? 0.0 : Float64(tail),
                       quadspec[1], quadspec[2], device, 0, 0)
   h = Ref{Ptr{Cvoid}}(C_NULL)
@@ -87,7 +91,7 @@ function AdaptiveKernelConfig(f; df=nothing, dim=1, alpha=0.0, tol::Float64=1e-8
   m = Ref{Int64}(0); k = Ref{Int64}(0)
   ccall((:sk_config_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Int64}, Ref{Int64}, Ptr{Cint}),
         h[], C_NULL, C_NULL, m, k, C_NULL)
-  cfg = AdaptiveKernelConfig(f, h[], fref, Int64(dim), Float64(alpha), tol, Bool(derivative), Bool(logw),
+  cfg = AdaptiveKernelConfig(f, h[], (fref, dfref), Int64(dim), Float64(alpha), tol, Bool(derivative), Bool(logw),
                              convergence_criteria, isnothing(tail) ? nothing : Float64(tail), (m[], k[]))
   finalizer(c -> ccall((:sk_config_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.handle), cfg)
   cfg

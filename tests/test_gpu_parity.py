@@ -197,8 +197,12 @@ def test_quadspec_warning_and_errors(sk):
     with pytest.raises(sk.SpectralKernelsError) as e:
         sk.AdaptiveKernelConfig(sk.SDF.exponential(1.0), alpha=1.5)
     assert e.value.code == 1
-    with pytest.raises(sk.SpectralKernelsError):
-        sk.AdaptiveKernelConfig(sk.SDF.exponential(1.0), logw=True)
+    with pytest.raises(sk.SpectralKernelsError) as e:  # src/quadrature.jl:221
+        sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5, 4), dim=4, alpha=0.5, logw=True)
+    assert e.value.code == 7 and "d > 2" in str(e.value)
+    with pytest.raises(sk.SpectralKernelsError) as e:  # src/quadrature.jl:194 needs df
+        sk.AdaptiveKernelConfig(lambda w: np.exp(-w), alpha=0.5, logw=True)
+    assert e.value.code == 1
     # NaN SDF: int1 and int2 are both NaN -> never accepted -> bisected down to b-a < 1e-16
     # (src/quadrature.jl:165 precedence quirk, src/utils.jl:28-36)
     bad = sk.AdaptiveKernelConfig(lambda w: w * float("nan"), quadspec=(8, 2))
@@ -272,3 +276,71 @@ def test_dim2_fast_hankel_vs_oracle_and_direct(sk, oracle, derivative, alpha):
     assert fast.last_stats()["n_panels"] == slow.last_stats()["n_panels"]
     if not derivative and alpha == 0.0:
         assert np.abs(b - oracle.matern_cov(big, parms, d=2)).max() / k0 <= 10 * 1e-8
+
+
+# ---- logw=true: the d/d(alpha) integrand (src/quadrature.jl:186-228, :243; src/derivatives.jl:74-81)
+
+LW_PARMS = (2.14, 0.97, 0.89)  # test/matern_sdf.jl:38
+
+
+@pytest.mark.parametrize("dim,alpha,n,hk", [
+    (1, 0.5, 1000, 0),    # test/matern_sdf.jl:40,69-85
+    (2, 1.5, 1000, -1),   # same test, dim 2: direct Bessel sums
+    (2, 1.5, 3000, 1),    # ... through the fast Hankel transform
+    (2, 0.4, 3000, 1),    # test/derivatives/nll_2d_sing.jl:35-38 (alpha = 0.4)
+])
+def test_logw_singularity_derivative(sk, oracle, dim, alpha, n, hk):
+    tol = 1e-8
+    rs = np.linspace(0.0, 1.1, n)
+    kw = dict(dim=dim, alpha=alpha, tol=tol)
+    mk = lambda mod: mod.SDF.matern(*LW_PARMS, dim)
+    k0 = sk.compute_k0(sk.AdaptiveKernelConfig(mk(sk), **kw))
+    cfg = sk.AdaptiveKernelConfig(mk(sk), logw=True, hankel_min_lags=hk, **kw)
+    ocfg = oracle.AdaptiveKernelConfig(mk(oracle), logw=True, **kw)
+    ks, errs = check_pair(sk, oracle, cfg, ocfg, rs, k0, tol, param_derivative=True)
+    # value at 0 is compute_k0 of the logw config (src/adaptive.jl:138-141)
+    assert abs(ks[0] - sk.compute_k0(cfg)) <= 1e-12 * abs(k0) and np.isnan(errs[0])
+    idx = np.arange(1, n, max(1, n // 60))
+    truth = oracle.sing_matern_cov_dalpha(rs[idx], alpha, LW_PARMS, d=dim)
+    assert np.abs(ks[idx] - truth).max() / abs(k0) <= 10 * tol
+
+
+@pytest.mark.parametrize("dim,alpha", [(1, 0.5), (2, 1.5), (2, 0.4)])
+def test_logw_bisected_first_panel(sk, oracle, dim, alpha):
+    # small rule: [0, b] is bisected, every left child takes the integration-by-parts route again
+    # (dim 1 keeps the reference's J_{-1/2} boundary term)
+    tol = 1e-8
+    rs = np.linspace(0.0, 1.1, 300)[1:]
+    kw = dict(dim=dim, alpha=alpha, tol=tol, quadspec=(64, 2))
+    mk = lambda mod: mod.SDF.matern(*LW_PARMS, dim)
+    k0 = sk.compute_k0(sk.AdaptiveKernelConfig(mk(sk), dim=dim, alpha=alpha, tol=tol))
+    cfg = sk.AdaptiveKernelConfig(mk(sk), logw=True, hankel_min_lags=-1, **kw)
+    ocfg = oracle.AdaptiveKernelConfig(mk(oracle), logw=True, **kw)
+    check_pair(sk, oracle, cfg, ocfg, rs, k0, tol, param_derivative=True)
+    assert sum(1 for r in cfg.last_trace() if r["a"] == 0.0) > 1
+
+
+def test_logw_callback_sdf_with_df(sk, oracle):
+    # callback SDF + df (what src/derivatives.jl:77-79 builds with AD), against the catalogue path
+    phi, rho, nu = LW_PARMS
+    e = -nu - 0.5
+    f = lambda w: phi * (rho * rho + w * w) ** e
+    df = lambda w: phi * e * 2.0 * w * (rho * rho + w * w) ** (e - 1.0)
+    rs = np.linspace(0.01, 1.1, 500)
+    kw = dict(dim=1, alpha=0.5, tol=1e-8, logw=True)
+    k0 = sk.compute_k0(sk.AdaptiveKernelConfig(sk.SDF.matern(*LW_PARMS, 1), dim=1, alpha=0.5))
+    a, ea = sk.kernel_values(sk.AdaptiveKernelConfig(f, df=df, **kw), rs, k0=k0, param_derivative=True)
+    b, eb = sk.kernel_values(sk.AdaptiveKernelConfig(sk.SDF.matern(*LW_PARMS, 1), **kw), rs, k0=k0, param_derivative=True)
+    assert np.abs(a - b).max() / abs(k0) <= 1e-12
+    ocfg = oracle.AdaptiveKernelConfig(f, df=df, **kw)
+    o, _ = oracle.kernel_values(ocfg, rs, k0=k0, param_derivative=True)
+    assert np.abs(a - o).max() / abs(k0) <= 1e-9
+
+
+def test_logw_without_singularity(sk, oracle):
+    # alpha = 0 (p = 0): no Jacobi panel, the integrand just carries log(w) (src/quadrature.jl:243) and the
+    # Legendre rule bisects towards the origin
+    rs = np.linspace(0.0, 2.0, 400)
+    cfg, ocfg = pair(sk, oracle, "matern", (1, 1, 1.5), logw=True, tol=1e-6, quadspec=(256, 16))
+    k0 = oracle.matern_cov(np.zeros(1), (1, 1, 1.5))[0]
+    check_pair(sk, oracle, cfg, ocfg, rs, k0, 1e-6, param_derivative=True)

@@ -62,6 +62,41 @@ def test_singular_matern_dim1(oracle, tol):
     assert abs(ks[0] - k0) == 0.0
 
 
+@pytest.mark.parametrize("dim", [1, 2])
+def test_singular_matern_derivative_in_alpha(oracle, dim):
+    # test/matern_sdf.jl:36-44,69-85 ("derivative in α"): logw=true, param_derivative=true, k0 = K(0);
+    # truth = d/d(alpha) of the 1F2 formula (mpmath).  Pins the integration-by-parts panel
+    # (src/quadrature.jl:186-228) for dim 1 (:cis kernels) and dim 2 (J0 / J1 kernels).
+    parms = (2.14, 0.97, 0.89)
+    alpha = (dim - 1) + 0.5
+    tol = 1e-8
+    xgrid = np.linspace(0.0, 1.1, 1000)[1::25]
+    sdf = oracle.SDF.matern(*parms, d=dim)
+    k0 = oracle.compute_k0(oracle.AdaptiveKernelConfig(sdf, dim=dim, alpha=alpha, tol=tol))
+    cfg = oracle.AdaptiveKernelConfig(sdf, dim=dim, alpha=alpha, tol=tol, logw=True)
+    ks, _ = oracle.kernel_values(cfg, xgrid, k0=k0, param_derivative=True)
+    truth = oracle.sing_matern_cov_dalpha(xgrid, alpha, parms, d=dim)
+    assert np.all(np.abs(ks - truth) / abs(k0) <= 10 * tol)
+
+
+def test_logw_dim1_boundary_term_is_the_reference_one(oracle):
+    # src/quadrature.jl:189 evaluates besselj(dim/2-1, .) also for dim = 1, i.e. J_{-1/2}(z) = sqrt(2/(pi z)) cos z
+    # where integration by parts gives cos z.  The term only matters when [0, b] is bisected (never with the
+    # default quadspec); the oracle keeps the reference's expression, so a bisected dim-1 run is off by far
+    # more than tol while dim 2 stays exact.  This test documents that the behaviour is intended.
+    parms = (2.14, 0.97, 0.89)
+    xs = np.linspace(0.0, 1.1, 50)[1:]
+    out = {}
+    for dim, alpha in ((1, 0.5), (2, 1.5)):
+        sdf = oracle.SDF.matern(*parms, d=dim)
+        k0 = oracle.compute_k0(oracle.AdaptiveKernelConfig(sdf, dim=dim, alpha=alpha))
+        cfg = oracle.AdaptiveKernelConfig(sdf, dim=dim, alpha=alpha, logw=True, quadspec=(64, 2))
+        ks, _, tr = oracle.kernel_values(cfg, xs, k0=k0, param_derivative=True, return_trace=True)
+        assert sum(1 for r in tr if r["a"] == 0.0) > 1
+        out[dim] = np.abs(ks - oracle.sing_matern_cov_dalpha(xs, alpha, parms, d=dim)).max() / abs(k0)
+    assert out[2] <= 1e-7 and out[1] > 1e-3
+
+
 def test_warping_lags(oracle):
     # test/derivatives/warping.jl:4-23: kernel_values(cfg, lags)[1] ~ closed form (rtol sqrt(eps))
     p1, p2 = 1 / 50.0, 1.1
