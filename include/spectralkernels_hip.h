@@ -111,6 +111,24 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
 int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double k0, int param_derivative,
                             double* d_vals, double* d_errs, void* stream);
 
+/* Callers' side of the path: lags from point pairs, generated on the device so that an n-point set never
+ * materialises its n(n-1)/2 lags on the host.
+ *   src/model.jl:64-65   warp_lags = [norm(warp_pts[j] - warp_pts[k]) for (j,k) in kernel_index_pairs]
+ *   src/utils.jl:43-46   xs = [0.0; |pts[i]-pts[j]| for i < j]             (pairs == NULL)
+ * pts: npts x pdim row-major coordinates; pairs: npairs x 2 zero-based indices, or NULL for the dense list
+ * "0 followed by all i < j" (then npairs is ignored and the output length is 1 + npts(npts-1)/2).
+ * vals/errs in pair order, as kernel_values on those lags would return them (src/model.jl:76). */
+int sk_kernel_values_pairs(sk_config* cfg, const double* pts, size_t npts, int pdim, const int64_t* pairs, size_t npairs,
+                           double k0, int has_k0, int param_derivative, double* vals_out, double* errs_out);
+/* the same on HBM-resident arrays (d_pts, d_pairs, d_vals, d_errs device pointers; d_pairs may be NULL) */
+int sk_kernel_values_pairs_device(sk_config* cfg, const double* d_pts, size_t npts, int pdim, const int64_t* d_pairs,
+                                  size_t npairs, double k0, int param_derivative, double* d_vals, double* d_errs,
+                                  void* stream);
+/* build_dense_cov_matrix(cfg, pts) -- src/utils.jl:41-64: the symmetric npt x npt matrix K(|p_i - p_j|), K(0) =
+ * compute_k0 on the diagonal; out: npt*npt doubles (host).  sk_dense_cov_matrix_device: d_pts, d_out in HBM. */
+int sk_dense_cov_matrix(sk_config* cfg, const double* pts, size_t npts, int pdim, double* out);
+int sk_dense_cov_matrix_device(sk_config* cfg, const double* d_pts, size_t npts, int pdim, double* d_out, void* stream);
+
 /* finufft1d3-level seam (src/utils.jl:10; src/quadrature.jl:109-110): for real coefficients
  * out_re/out_im[i] = sum_j coef[j] * exp(2*pi*i * nodes[j] * xs[i]).  Host pointers.
  * method: 0 = type-3 NUFFT kernels (nodes must lie in [lo, hi], xs >= 0), 1 = direct-sum kernel. */

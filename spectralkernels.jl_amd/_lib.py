@@ -57,6 +57,10 @@ def load():
     L.sk_compute_k0.argtypes = [vp, dp]
     L.sk_kernel_values.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp]
     L.sk_kernel_values_device.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_int, vp, vp, vp]
+    L.sk_kernel_values_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp]
+    L.sk_kernel_values_pairs_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_double, C.c_int, vp, vp, vp]
+    L.sk_dense_cov_matrix.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+    L.sk_dense_cov_matrix_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]
     L.sk_panel_sums.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_double, vp, C.c_size_t, C.c_int, vp, vp]
     L.sk_last_stats.argtypes = [vp, C.POINTER(Stats)]
     L.sk_last_trace.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]

@@ -194,6 +194,43 @@ def kernel_values_device(config, d_xs_ptr, n, k0, d_vals_ptr, d_errs_ptr, param_
                                             C.c_void_p(d_errs_ptr), C.c_void_p(stream_ptr)))
 
 
+def _points(pts):
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    if pts.ndim == 1:
+        pts = pts.reshape(-1, 1)
+    return pts
+
+
+def kernel_values_pairs(config, pts, pairs=None, k0=None, param_derivative=False):
+    """Kernel values at the lags of point pairs, the lags being formed on the device:
+    norm(pts[j] - pts[k]) for (j, k) in pairs (src/model.jl:64-65,76; zero-based indices), or, with
+    pairs=None, the dense list [0; |p_i - p_j| for i < j] of build_dense_cov_matrix (src/utils.jl:43-46).
+    pts: (npts,) or (npts, pdim).  Returns (vals, errs) in pair order."""
+    pts = _points(pts)
+    npts, pdim = pts.shape
+    if pairs is None:
+        n, pp, npairs = 1 + npts * (npts - 1) // 2, None, 0
+    else:
+        pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+        n, pp, npairs = pairs.shape[0], pairs.ctypes.data_as(C.c_void_p), pairs.shape[0]
+    vals, errs = np.zeros(n), np.zeros(n)
+    _check(L.load().sk_kernel_values_pairs(config._h, pts.ctypes.data_as(C.c_void_p), npts, pdim, pp, npairs,
+                                           0.0 if k0 is None else float(k0), 0 if k0 is None else 1,
+                                           int(bool(param_derivative)), vals.ctypes.data_as(C.c_void_p),
+                                           errs.ctypes.data_as(C.c_void_p)))
+    return vals, errs
+
+
+def build_dense_cov_matrix(config, pts):
+    """build_dense_cov_matrix(cfg, pts) -- src/utils.jl:41-64: K(|p_i - p_j|) as a dense symmetric matrix."""
+    pts = _points(pts)
+    npts, pdim = pts.shape
+    out = np.zeros((npts, npts))
+    _check(L.load().sk_dense_cov_matrix(config._h, pts.ctypes.data_as(C.c_void_p), npts, pdim,
+                                        out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 def panel_sums(config, nodes, coef, lo, hi, xs, method="nufft"):
     """finufft1d3(nodes, coef, xs) (src/utils.jl:10): sum_j coef_j exp(2 pi i nodes_j xs_i) on the device."""
     nodes = np.ascontiguousarray(nodes, dtype=np.float64)

@@ -81,6 +81,10 @@ struct sk_config {
   size_t ws_bytes = 0;
   double* d_io = nullptr;          // staging of sk_kernel_values (host arrays)
   size_t io_bytes = 0;
+  double* d_lags = nullptr;        // values / errors staging of the pair entries (3 n doubles)
+  size_t lags_bytes = 0;
+  double* d_plags = nullptr;       // pairwise lags generated on the device
+  size_t pl_bytes = 0;
   HostStatus* h_status = nullptr;  // pinned + device-mapped, written by k_advance
   unsigned int seq = 0;
   size_t trace_len = 0;
@@ -830,6 +834,8 @@ void sk_config_destroy(sk_config* cfg) {
   for (void* p : cfg->owned) hipFree(p);
   if (cfg->ws) hipFree(cfg->ws);
   if (cfg->d_io) hipFree(cfg->d_io);
+  if (cfg->d_lags) hipFree(cfg->d_lags);
+  if (cfg->d_plags) hipFree(cfg->d_plags);
   if (cfg->h_status) hipHostFree(cfg->h_status);
   if (cfg->h_nuniq) hipHostFree(cfg->h_nuniq);
   if (cfg->own_stream) hipStreamDestroy(cfg->own_stream);
@@ -909,6 +915,122 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
         hipStreamSynchronize(st) != hipSuccess)
       rc = fail(SK_EHIP, "D2H copy failed");
   }
+  return rc;
+}
+
+// grow-only buffer of 3 n doubles: lags, values, errors of the pair entries
+static int ensure_lags(sk_config* cfg, size_t n) {
+  const size_t need = 3 * n * sizeof(double);
+  if (need <= cfg->lags_bytes) return SK_OK;
+  if (cfg->d_lags) HIPCHK(hipFree(cfg->d_lags));
+  cfg->d_lags = nullptr;
+  cfg->lags_bytes = 0;
+  HIPCHK(hipMalloc((void**)&cfg->d_lags, need + need / 4));
+  cfg->lags_bytes = need + need / 4;
+  return SK_OK;
+}
+static size_t pair_count(size_t npts, const void* pairs, size_t npairs) {
+  return pairs ? npairs : 1 + npts * (npts - 1) / 2;
+}
+
+int sk_kernel_values_pairs_device(sk_config* cfg, const double* d_pts, size_t npts, int pdim, const int64_t* d_pairs,
+                                  size_t npairs, double k0, int param_derivative, double* d_vals, double* d_errs,
+                                  void* stream) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  if (pdim < 1 || npts < 1) return fail(SK_EINVAL, "need at least one point and pdim >= 1");
+  const size_t n = pair_count(npts, d_pairs, npairs);
+  if (n == 0) return SK_OK;
+  HIPCHK(hipSetDevice(cfg->device));
+  // lags in a buffer of their own: the march's workspace may be reallocated by the call below
+  size_t need = n * sizeof(double);
+  if (need > cfg->pl_bytes) {
+    if (cfg->d_plags) HIPCHK(hipFree(cfg->d_plags));
+    cfg->d_plags = nullptr;
+    cfg->pl_bytes = 0;
+    HIPCHK(hipMalloc((void**)&cfg->d_plags, need + need / 4));
+    cfg->pl_bytes = need + need / 4;
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : cfg->own_stream;
+  launch_pair_lags(d_pts, (long long)npts, pdim, (const long long*)d_pairs, (long long)n, cfg->d_plags, st);
+  return sk_kernel_values_device(cfg, cfg->d_plags, n, k0, param_derivative, d_vals, d_errs, st);
+}
+
+int sk_kernel_values_pairs(sk_config* cfg, const double* pts, size_t npts, int pdim, const int64_t* pairs, size_t npairs,
+                           double k0, int has_k0, int param_derivative, double* vals_out, double* errs_out) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  if (pdim < 1 || npts < 1) return fail(SK_EINVAL, "need at least one point and pdim >= 1");
+  if (!has_k0) {
+    int rc = sk_compute_k0(cfg, &k0);
+    if (rc) return rc;
+  }
+  const size_t n = pair_count(npts, pairs, npairs);
+  if (n == 0) return SK_OK;
+  HIPCHK(hipSetDevice(cfg->device));
+  int rc = ensure_lags(cfg, n);
+  if (rc) return rc;
+  hipStream_t st = cfg->own_stream;
+  double* d_pts = nullptr;
+  int64_t* d_pairs = nullptr;
+  HIPCHK(hipMalloc((void**)&d_pts, npts * pdim * sizeof(double)));
+  if (pairs && hipMalloc((void**)&d_pairs, 2 * npairs * sizeof(int64_t)) != hipSuccess) {
+    (void)hipFree(d_pts);
+    return fail(SK_EHIP, "hipMalloc(pairs) failed");
+  }
+  if (hipMemcpyAsync(d_pts, pts, npts * pdim * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+      (pairs && hipMemcpyAsync(d_pairs, pairs, 2 * npairs * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess))
+    rc = fail(SK_EHIP, "H2D copy failed");
+  double* d = cfg->d_lags;
+  if (!rc) rc = sk_kernel_values_pairs_device(cfg, d_pts, npts, pdim, d_pairs, npairs, k0, param_derivative, d + n, d + 2 * n, st);
+  if (!rc) {
+    if (hipMemcpyAsync(vals_out, d + n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(errs_out, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
+      rc = fail(SK_EHIP, "D2H copy failed");
+  }
+  if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(SK_EHIP, "stream synchronisation failed");
+  (void)hipFree(d_pts);
+  if (d_pairs) (void)hipFree(d_pairs);
+  return rc;
+}
+
+int sk_dense_cov_matrix_device(sk_config* cfg, const double* d_pts, size_t npts, int pdim, double* d_out, void* stream) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  if (pdim < 1 || npts < 1) return fail(SK_EINVAL, "need at least one point and pdim >= 1");
+  double k0;
+  int rc = sk_compute_k0(cfg, &k0);  // src/utils.jl:51: kernel_values without k0
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(cfg->device));
+  const size_t n = 1 + npts * (npts - 1) / 2;
+  rc = ensure_lags(cfg, n);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : cfg->own_stream;
+  double* d = cfg->d_lags;
+  rc = sk_kernel_values_pairs_device(cfg, d_pts, npts, pdim, nullptr, 0, k0, 0, d + n, d + 2 * n, st);
+  if (rc) return rc;
+  launch_fill_cov(d + n, (long long)npts, d_out, st);
+  HIPCHK(hipStreamSynchronize(st));
+  return SK_OK;
+}
+
+int sk_dense_cov_matrix(sk_config* cfg, const double* pts, size_t npts, int pdim, double* out) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  if (pdim < 1 || npts < 1) return fail(SK_EINVAL, "need at least one point and pdim >= 1");
+  HIPCHK(hipSetDevice(cfg->device));
+  hipStream_t st = cfg->own_stream;
+  double *d_pts = nullptr, *d_out = nullptr;
+  HIPCHK(hipMalloc((void**)&d_pts, npts * pdim * sizeof(double)));
+  if (hipMalloc((void**)&d_out, npts * npts * sizeof(double)) != hipSuccess) {
+    (void)hipFree(d_pts);
+    return fail(SK_EHIP, "hipMalloc(matrix) failed");
+  }
+  int rc = SK_OK;
+  if (hipMemcpyAsync(d_pts, pts, npts * pdim * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+    rc = fail(SK_EHIP, "H2D copy failed");
+  if (!rc) rc = sk_dense_cov_matrix_device(cfg, d_pts, npts, pdim, d_out, st);
+  if (!rc && (hipMemcpyAsync(out, d_out, npts * npts * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipStreamSynchronize(st) != hipSuccess))
+    rc = fail(SK_EHIP, "D2H copy failed");
+  (void)hipFree(d_pts);
+  (void)hipFree(d_out);
   return rc;
 }
 

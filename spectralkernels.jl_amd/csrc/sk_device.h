@@ -180,6 +180,11 @@ void launch_seam_interp(const DevConst& dc, const EsConst* ec, const double2* ff
 void launch_direct(const double* nodes, const double* coef, int64_t M, const double* xs, int64_t n, double* out_re,
                    double* out_im, hipStream_t st);
 
+// callers' side: pairwise lags and the dense covariance matrix (src/model.jl:64-65, src/utils.jl:41-64)
+void launch_pair_lags(const double* pts, long long npts, int pdim, const long long* pairs, long long npairs, double* lags,
+                      hipStream_t st);
+void launch_fill_cov(const double* vals, long long npts, double* out, hipStream_t st);
+
 // sort / dedup helpers
 void launch_check_sorted(const double* xs, long long n, int* flags, hipStream_t st);  // flags[0]=not strictly increasing, flags[1]=invalid (<0 or NaN)
 size_t sort_unique_temp_bytes(long long n);

@@ -1493,6 +1493,70 @@ void launch_direct(const double* nodes, const double* coef, int64_t M, const dou
 
 // ------------------------------------------------------------------ sort / dedup (src/adaptive.jl:99-120)
 
+// lags of point pairs (src/model.jl:65 norm(p_j - p_k)); pairs == nullptr: the dense list of
+// build_dense_cov_matrix (src/utils.jl:43-46), entry 0 is the lag 0 and entry 1 + i*npts - i(i+1)/2 + (j-i-1)
+// is |p_i - p_j| for i < j
+__device__ __forceinline__ void dense_pair(long long e, long long npts, long long& i, long long& j) {
+  // rows before i hold i*npts - i(i+1)/2 pairs: invert with a float estimate, then correct
+  const double nn = (double)npts - 0.5;
+  long long ii = (long long)floor(nn - sqrt(fmax(nn * nn - 2.0 * (double)e, 0.0)));
+  ii = ii < 0 ? 0 : (ii > npts - 2 ? npts - 2 : ii);
+  while (ii > 0 && ii * npts - ii * (ii + 1) / 2 > e) --ii;
+  while ((ii + 1) * npts - (ii + 1) * (ii + 2) / 2 <= e) ++ii;
+  i = ii;
+  j = ii + 1 + (e - (ii * npts - ii * (ii + 1) / 2));
+}
+__global__ void k_pair_lags(const double* pts, long long npts, int pdim, const long long* pairs, long long npairs,
+                            double* lags) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npairs) return;
+  long long i, j;
+  if (pairs) {
+    i = pairs[2 * e];
+    j = pairs[2 * e + 1];
+    if (i < 0 || j < 0 || i >= npts || j >= npts) {  // reported as an invalid lag by the input check
+      lags[e] = __builtin_nan("");
+      return;
+    }
+  } else {
+    if (e == 0) {
+      lags[0] = 0.0;
+      return;
+    }
+    dense_pair(e - 1, npts, i, j);
+  }
+  double s = 0.0;
+  if (pdim == 1) {
+    s = fabs(pts[i] - pts[j]);
+  } else {
+    for (int q = 0; q < pdim; ++q) {
+      const double d = pts[i * pdim + q] - pts[j * pdim + q];
+      s = fma(d, d, s);
+    }
+    s = sqrt(s);
+  }
+  lags[e] = s;
+}
+void launch_pair_lags(const double* pts, long long npts, int pdim, const long long* pairs, long long npairs, double* lags,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(k_pair_lags, dim3(nblk(npairs, 256)), dim3(256), 0, st, pts, npts, pdim, pairs, npairs, lags);
+}
+// src/utils.jl:54-61: symmetric fill from the dense pair list
+__global__ void k_fill_cov(const double* vals, long long npts, double* out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npts * npts) return;
+  const long long r = e / npts, c = e - r * npts;
+  if (r == c) {
+    out[e] = vals[0];
+    return;
+  }
+  const long long i = r < c ? r : c, j = r < c ? c : r;
+  out[e] = vals[1 + i * npts - i * (i + 1) / 2 + (j - i - 1)];
+}
+void launch_fill_cov(const double* vals, long long npts, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_fill_cov, dim3(nblk(npts * npts, 256)), dim3(256), 0, st, vals, npts, out);
+}
+
 __global__ void k_check_sorted(const double* xs, long long n, int* flags) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -344,3 +344,46 @@ def test_logw_without_singularity(sk, oracle):
     cfg, ocfg = pair(sk, oracle, "matern", (1, 1, 1.5), logw=True, tol=1e-6, quadspec=(256, 16))
     k0 = oracle.matern_cov(np.zeros(1), (1, 1, 1.5))[0]
     check_pair(sk, oracle, cfg, ocfg, rs, k0, 1e-6, param_derivative=True)
+
+
+# ---- callers' side: pairwise lags formed on the device (src/model.jl:64-65, src/utils.jl:41-64)
+
+def test_pairwise_lags_and_dense_cov_matrix(sk, oracle):
+    rng = np.random.default_rng(5)
+    pts = np.sort(rng.uniform(0.0, 3.0, 40))
+    pts[7] = pts[6]  # coincident points -> lag 0 off the diagonal
+    cfg, ocfg = pair(sk, oracle, "matern", (1, 1, 1.5), quadspec=(256, 16))
+    k0 = oracle.matern_cov(np.zeros(1), (1, 1, 1.5))[0]
+    # build_dense_cov_matrix (src/utils.jl:41-64) against the oracle on host-built lags
+    K = sk.build_dense_cov_matrix(cfg, pts)
+    lags = np.abs(pts[:, None] - pts[None, :])
+    ok, _ = oracle.kernel_values(ocfg, lags.ravel(), k0=k0)
+    assert np.abs(K - ok.reshape(40, 40)).max() / k0 <= 1e-9
+    assert np.array_equal(K, K.T) and abs(K[0, 0] - sk.compute_k0(cfg)) <= 1e-14
+    assert np.abs(K - oracle.matern_cov(lags, (1, 1, 1.5))).max() / k0 <= 10 * 1e-8
+    # dense pair list == explicit list of the same pairs == kernel_values on host-built lags
+    v0, e0 = sk.kernel_values_pairs(cfg, pts, k0=k0)
+    iu = np.triu_indices(40, 1)
+    pairs = np.stack(iu, axis=1)
+    v1, e1 = sk.kernel_values_pairs(cfg, pts, pairs, k0=k0)
+    v2, e2 = sk.kernel_values(cfg, lags[iu], k0=k0)
+    assert v0[0] == k0 and np.isnan(e0[0])
+    assert np.array_equal(v0[1:], v1) and np.array_equal(v1, v2) and np.array_equal(e1, e2, equal_nan=True)
+
+
+def test_pairwise_lags_2d_points_isotropic_kernel(sk, oracle):
+    # gen_kernel_setup (src/model.jl:64-65): norm of the difference of 2-D (warped) points, dim-2 kernel
+    rng = np.random.default_rng(6)
+    pts = rng.uniform(0.0, 1.0, (60, 2))
+    pairs = rng.integers(0, 60, (500, 2))
+    parms = (2.14, 0.97, 0.89)
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, 2), dim=2, quadspec=(256, 16), hankel_min_lags=-1)
+    ocfg = oracle.AdaptiveKernelConfig(oracle.SDF.matern(*parms, 2), dim=2, quadspec=(256, 16))
+    k0 = float(oracle.matern_cov(0.0, parms, d=2))
+    v, e = sk.kernel_values_pairs(cfg, pts, pairs, k0=k0)
+    lags = np.linalg.norm(pts[pairs[:, 0]] - pts[pairs[:, 1]], axis=1)
+    ov, _ = oracle.kernel_values(ocfg, lags, k0=k0)
+    assert np.abs(v - ov).max() / k0 <= 1e-9
+    with pytest.raises(sk.SpectralKernelsError) as ex:  # index out of range
+        sk.kernel_values_pairs(cfg, pts, np.array([[0, 60]]), k0=k0)
+    assert ex.value.code == 1
