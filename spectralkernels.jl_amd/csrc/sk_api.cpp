@@ -267,6 +267,7 @@ static hipEvent_t ev_get(sk_config* cfg) {
 // SK_DEBUG_SYNC=1: name every launch group on stderr and synchronise after it, so that an asynchronous
 // GPU fault can be attributed to a kernel (diagnostics only; serialises the pipeline).
 static const bool g_debug_sync = getenv("SK_DEBUG_SYNC") != nullptr;
+static const bool g_no_fuse = getenv("SK_NO_FUSE") != nullptr;  // diagnostics: separate k_gen and k_spread launches
 static const char* const k_names[SK_K_COUNT] = {"k_gen", "k_spread", "rocfft", "k_interp", "k_advance"};
 
 struct EvScope {
@@ -380,9 +381,14 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       int rc = upload_fvals(g, hv);
       if (rc) return rc;
     }
-    { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, g, st); }
+    const bool fused = !host_step && cfg->dc.dim == 1 && !g_no_fuse;  // catalogue SDF, no log factors
+    if (!fused) { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, g, st); }
     if (cfg->dc.dim == 1) {
-      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->d_ec, db, t & 1, st); }
+      {
+        EvScope e(cfg, st, SK_K_SPREAD);
+        if (fused) launch_genspread(cfg->dc, cfg->d_ec, db, mode, t, n, k0, ks0, st);
+        else launch_spread(cfg->dc, cfg->d_ec, db, t & 1, st);
+      }
       {
         EvScope e(cfg, st, SK_K_FFT);
         int rc = run_fft(cfg, st);
@@ -676,6 +682,10 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   dc.alpha = args->alpha; dc.p = cfg->p; dc.c = cfg->c; dc.tol = args->tol; dc.tail = args->tail;
   dc.sdf_kind = args->sdf_kind;
   std::memcpy(dc.sdf_prm, args->sdf_params, sizeof(dc.sdf_prm));
+  if (dc.sdf_kind == SK_SDF_MATERN) {  // device fast path for half-integer exponents (sdf_eval_dev)
+    const double h = 2.0 * (dc.sdf_prm[2] + 0.5 * dc.sdf_prm[3]);
+    dc.sdf_prm[4] = (h == std::floor(h) && h >= 1.0 && h <= 64.0) ? h : 0.0;
+  }
   dc.w = choose_width(*args);
   {
     int64_t need = (int64_t)std::ceil(0.99 * (double)cfg->M) + dc.w;

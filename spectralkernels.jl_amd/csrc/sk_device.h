@@ -159,6 +159,9 @@ void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t
 void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0, int g,
                 hipStream_t st);
 void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st);
+// k_gen + k_spread in one launch (catalogue SDFs, dim 1, device-resident march)
+void launch_genspread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int mode, int t, long long n, double k0,
+                      double ks0, hipStream_t st);
 void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long n, int nu, int raw, hipStream_t st);
 // logw first panel: combine the raw sums of passes A and B with the boundary term (src/quadrature.jl:189,224-225)
 void launch_lw_finish(const DevConst& dc, const DevBuffers& db, int slot, long long n, double B0, hipStream_t st);

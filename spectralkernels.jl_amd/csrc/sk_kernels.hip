@@ -59,7 +59,21 @@ __device__ __forceinline__ double2 cis_turns_prod(double a, double b) {
 
 __device__ __forceinline__ double sdf_eval_dev(int kind, const double* prm, double w) {
   switch (kind) {
-    case SK_SDF_MATERN: return prm[0] * pow(prm[1] * prm[1] + w * w, -prm[2] - prm[3] * 0.5);
+    case SK_SDF_MATERN: {
+      const double x = prm[1] * prm[1] + w * w;
+      // prm[4] (set by sk_config_create): 2 (nu + d/2) when that is an integer <= 64, else 0.  Half-integer
+      // powers by sqrt and repeated squaring (~2 ulp) instead of the generic pow (~250 instructions).
+      const int h = (int)prm[4];
+      if (h > 0) {
+        double b = (h & 1) ? sqrt(x) : 1.0, sq = x, r = 1.0;
+        for (int e = h >> 1; e > 0; e >>= 1) {
+          if (e & 1) r *= sq;
+          sq *= sq;
+        }
+        return prm[0] / (r * b);
+      }
+      return prm[0] * pow(x, -prm[2] - prm[3] * 0.5);
+    }
     case SK_SDF_EXPONENTIAL: return exp(-prm[0] * fabs(w));
     case SK_SDF_GAUSSIAN: return exp(-(w * w) / (prm[0] * prm[0]));
     default: return __builtin_nan("");
@@ -267,11 +281,10 @@ __device__ void transition(DevState& s, const DevConst& dc, const DevBuffers& db
 //   ASIS        state_t was already written by k_advance.
 // The workgroup with blockIdx 0 publishes it to db.state[t & 1] and performs the side effects.
 __device__ void step_state(DevState& sh, const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0,
-                           double ks0) {
+                           double ks0, bool lead) {
   __shared__ double r_max;
   __shared__ unsigned int r_hi;
   __shared__ int r_nan;
-  const bool lead = (blockIdx.x == 0);
   if (mode == SK_MODE_TRANSITION && threadIdx.x < 64) {
     const Reductions& rd = db.red[(t - 1) & 1];
     double m = __longlong_as_double((long long)rd.max_bits[threadIdx.x]);
@@ -331,7 +344,7 @@ __global__ void k_tail(DevConst dc, DevBuffers db, int slot) {
 __global__ void __launch_bounds__(64) k_advance(DevConst dc, DevBuffers db, int mode, int t, long long n, double k0,
                                                  double ks0, unsigned int seq) {
   __shared__ DevState sh;
-  step_state(sh, dc, db, mode, t, n, k0, ks0);
+  step_state(sh, dc, db, mode, t, n, k0, ks0, blockIdx.x == 0);
   if (threadIdx.x == 0) {
     HostStatus* hs = db.host_status;
     hs->state = sh;
@@ -380,25 +393,56 @@ constexpr int kWinCap = 320;     // k_interp: largest FFT-output window (samples
 constexpr int kTileCells = 64;   // spread-grid cells per workgroup
 constexpr int kSpreadThreads = 256;
 
+// src/adaptive.jl:99,113: is the input strictly increasing (=> already unique and sorted) and valid?
+// Folded into the first kernel of a call (grid-stride over the lags) instead of a launch of its own.
+__device__ __forceinline__ void check_input_lags(const DevBuffers& db, long long n) {
+  bool bad = false, unsorted = false;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double x = db.xs[i];
+    bad |= !(x >= 0.0);
+    unsorted |= (i + 1 < n) && !(x < db.xs[i + 1]);
+  }
+  if (__any(unsorted) && (threadIdx.x & 63) == 0 && !db.flags[0]) atomicOr(&db.flags[0], 1);
+  if (__any(bad) && (threadIdx.x & 63) == 0 && !db.flags[1]) atomicOr(&db.flags[1], 1);
+}
+
+// Node, Gauss weight and SDF value of quadrature node j of `rule` (updatequadbufs!, src/quadrature.jl:49-95):
+// returns the real strength c_j = weight * w^p * S(w) and the node w.  Catalogue SDFs, no log factors.
+struct NodeRef { double no, wt; int sp; };
+__device__ __forceinline__ NodeRef node_fetch(const DevConst& dc, int jacobi, int rule, int j) {
+  const int mr = (int)(rule ? 2 * dc.m : dc.m);
+  NodeRef r;
+  r.sp = j / mr;
+  const int q = j - r.sp * mr;
+  if (jacobi && r.sp == 0) {
+    r.no = (rule ? dc.jac_no2 : dc.jac_no1)[q];
+    r.wt = (rule ? dc.jac_wt2 : dc.jac_wt1)[q];
+  } else {
+    r.no = (rule ? dc.leg_no2 : dc.leg_no1)[q];
+    r.wt = (rule ? dc.leg_wt2 : dc.leg_wt1)[q];
+  }
+  return r;
+}
+__device__ __forceinline__ double node_strength(const DevConst& dc, const PanelParams& pp, const NodeRef& nr) {
+  const int sp = nr.sp;
+  const double pa = pp.pa, pb = pp.pb;
+  const double sa = (sp == 0) ? pa : pa + (pb - pa) * ((double)sp / (double)dc.k);
+  const double sb = (sp + 1 == dc.k) ? pb : pa + (pb - pa) * ((double)(sp + 1) / (double)dc.k);
+  const double bmad2 = 0.5 * (sb - sa), bpad2 = 0.5 * (sb + sa);
+  const double w = bmad2 * nr.no + bpad2;
+  double wq;
+  if (pp.jacobi && sp == 0) wq = nr.wt * pow(bmad2, dc.p + 1.0);             // src/quadrature.jl:61-78
+  else wq = nr.wt * bmad2 * (dc.p == 0.0 ? 1.0 : pow(w, dc.p));               // src/quadrature.jl:82-92
+  return wq * sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, w);
+}
 // k_gen: one thread per quadrature node of the current (sub)panel, both rules: node, SDF value,
 // Gauss weight (updatequadbufs!, src/quadrature.jl:49-95) and the type-3 pre-phase; writes the
 // complex source strengths c'_j (rule 1: M entries, then rule 2: 2M entries).
 __global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mode, int t, long long n, double k0,
                                              double ks0, int g) {
   __shared__ DevState sh;
-  step_state(sh, dc, db, mode, t, n, k0, ks0);
-  if (mode == SK_MODE_INIT && db.check_input) {
-    // src/adaptive.jl:99,113: is the input strictly increasing (=> already unique and sorted) and valid?
-    // Folded into the first k_gen (grid-stride over the lags) instead of a launch of its own.
-    bool bad = false, unsorted = false;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-      const double x = db.xs[i];
-      bad |= !(x >= 0.0);
-      unsorted |= (i + 1 < n) && !(x < db.xs[i + 1]);
-    }
-    if (__any(unsorted) && (threadIdx.x & 63) == 0 && !db.flags[0]) atomicOr(&db.flags[0], 1);
-    if (__any(bad) && (threadIdx.x & 63) == 0 && !db.flags[1]) atomicOr(&db.flags[1], 1);
-  }
+  step_state(sh, dc, db, mode, t, n, k0, ks0, blockIdx.x == 0);
+  if (mode == SK_MODE_INIT && db.check_input) check_input_lags(db, n);
   if (sh.done) return;
   if (!state_sane(sh, db, n)) return;
   const PanelParams pp = sh.pp;
@@ -452,144 +496,192 @@ __global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mod
 // first cell, its W kernel weights); then every cell gathers from the staged batch in a fixed order
 // (lane = cell, the 4 waves split the cell's contiguous source range; deterministic, no atomics).
 // The tile is deconvolved, centred with (-1)^l and written in FFT order.
-template <int W>
-__global__ void __launch_bounds__(kSpreadThreads) k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot) {
+// FUSED (catalogue SDFs, dim 1, no log factors): the kernel is also k_gen -- every workgroup derives the state
+// of step t itself (step_state; the last, otherwise idle pad workgroup is the one that publishes it) and the
+// staging thread of a source computes its strength instead of reading it: one launch and one round trip
+// through HBM less per panel.  `slot_or_t` is the step counter t then, the state slot otherwise.
+template <int W, bool FUSED>
+__global__ void __launch_bounds__(kSpreadThreads) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode, long long n, double k0, double ks0) {
   __shared__ double s_w[kSpreadThreads * (W + 1)];
   __shared__ double2 s_c[kSpreadThreads];
   __shared__ int s_l0[kSpreadThreads];
   __shared__ double2 s_red[kSpreadThreads];
   __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
-  const DevState& s = db.state[slot];
+  __shared__ DevState sh;
+  const int slot = FUSED ? (slot_or_t & 1) : slot_or_t;
+  if constexpr (FUSED) {
+    step_state(sh, dc, db, mode, slot_or_t, n, k0, ks0, blockIdx.x == gridDim.x - 1);
+    if (mode == SK_MODE_INIT && db.check_input) check_input_lags(db, n);
+  }
+  const DevState& s = FUSED ? sh : db.state[slot];
   if (s.done) return;
   if (!state_sane(s, db, s.n)) return;
-  const int variant = s.pp.jacobi;
+  const int variant = FUSED ? __builtin_amdgcn_readfirstlane(s.pp.jacobi) : s.pp.jacobi;
   const int64_t n1 = dc.n1, n2 = dc.n2;
   const int ntiles = dc.ntiles[variant];
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= ntiles) {
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) resolve_tail(db.state[slot], dc);  // off the critical path
-    // zero padding of the FFT input: indices [n1 - n1/2, n2 - n1/2) of both rules
-    const int64_t npad = n2 - n1;
-    int64_t g = ((int64_t)blockIdx.x - ntiles) * kSpreadThreads + tid;
-    if (g < 2 * npad) {
-      const int rule = g >= npad ? 1 : 0;
-      const int64_t off = rule ? g - npad : g;
-      db.fft[(int64_t)rule * n2 + (n1 - n1 / 2) + off] = make_double2(0.0, 0.0);
-    }
-    return;
+  PanelParams pp;
+  if constexpr (FUSED) {
+    // wave-uniform values read from LDS: move them to SGPRs
+    auto uni = [](double v) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    pp.pa = uni(sh.pp.pa);
+    pp.pb = uni(sh.pp.pb);
+    pp.kappa = uni(sh.pp.kappa);
+    pp.jacobi = variant;
   }
-#ifdef SK_STAMPS
-  unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-#endif
-  const int4 tl = dc.tiles[variant][blockIdx.x];  // {rule<<30 | first cell, cells, first source, end source}
-  const int rule = (tl.x >> 30) & 1;
-  const int L0 = tl.x & 0x3fffffff;
-  const int ncell = tl.y;
-  const int jlo = tl.z, jhi = tl.w;
-  const int* __restrict__ cs = dc.cellstart[variant][rule];
-  const double* __restrict__ pos = dc.pos[variant][rule];
-  const double2* __restrict__ src = db.src + (rule ? dc.M : 0);
-  // first batch's loads are issued before the table staging barrier
-  double P_next = 0.0;
-  double2 c_next = make_double2(0.0, 0.0);
-  if (jlo + tid < jhi) {
-    P_next = pos[jlo + tid];
-    c_next = src[jlo + tid];
-  }
-  // lane mapping: tiles at the sub-panel edges have few cells but many sources, so the 64 lanes of
-  // a wave are split as (cell, sub): `spl` lanes share one cell and take strided sources
-  int c2 = 64;
-  while (c2 / 2 >= ncell && c2 > 1) c2 >>= 1;  // smallest power of two >= ncell (<= 64)
-  const int spl = 64 / c2;
-  const int lane = tid & 63;
-  const int part = tid >> 6;
-  constexpr int NPART = kSpreadThreads / 64;
-  const int cell = lane / spl, sub = lane - cell * spl;
-  // sources touching cell L have floor(P_j) in [L - W/2, L + W/2): a contiguous range of the sorted list
-  int J0 = 0, J1 = 0;
-  if (cell < ncell) {
-    const int L = L0 + cell;
-    J0 = cs[L - W / 2 < 0 ? 0 : L - W / 2];
-    J1 = cs[L + W / 2 > (int)n1 ? (int)n1 : L + W / 2];
-  }
-  stage_es_tables<W>(ec, s_poly, nullptr);
-  __syncthreads();
-#ifdef SK_STAMPS
-  t1 = __builtin_amdgcn_s_memtime();
-#endif
-  double ar = 0.0, ai = 0.0;
-  for (int jb = jlo; jb < jhi; jb += kSpreadThreads) {
-    const int j = jb + tid;
-    const int nb = (jhi - jb) < kSpreadThreads ? (jhi - jb) : kSpreadThreads;
-    if (j < jhi) {
-      const double P = P_next;
-      s_c[tid] = c_next;
-      if (j + kSpreadThreads < jhi) {  // prefetch the next batch
-        P_next = pos[j + kSpreadThreads];
-        c_next = src[j + kSpreadThreads];
+  stage_es_tables<W>(ec, s_poly, nullptr);  // made visible by the first barrier of the tile loop
+  // Work items: the variant's tiles (heaviest first), then the zero padding of the FFT input.  The separate
+  // kernel is launched with one workgroup per item; the fused one with a grid that is resident at once, so
+  // that the state prologue is paid once per workgroup slot (items are taken with stride gridDim.x).
+  const int npadblk = (int)((2 * (n2 - n1) + kSpreadThreads - 1) / kSpreadThreads);
+  for (int item = blockIdx.x; item < ntiles + npadblk; item += gridDim.x) {
+    if (item >= ntiles) {
+      // zero padding of the FFT input: indices [n1 - n1/2, n2 - n1/2) of both rules
+      const int64_t npad = n2 - n1;
+      const int64_t g = ((int64_t)item - ntiles) * kSpreadThreads + tid;
+      if (g < 2 * npad) {
+        const int rule = g >= npad ? 1 : 0;
+        const int64_t off = rule ? g - npad : g;
+        db.fft[(int64_t)rule * n2 + (n1 - n1 / 2) + off] = make_double2(0.0, 0.0);
       }
-      const double tcn = P - 0.5 * W;
-      const double l0d = ceil(tcn);
-      const double y = (l0d - tcn) - 0.5;
-      const double y2 = y * y;
-      s_l0[tid] = (int)l0d - L0;
-      double* wrow = &s_w[tid * (W + 1)];
+      continue;
+    }
+#ifdef SK_STAMPS
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#endif
+    const int4 tl = dc.tiles[variant][item];  // {rule<<30 | first cell, cells, first source, end source}
+    const int rule = (tl.x >> 30) & 1;
+    const int L0 = tl.x & 0x3fffffff;
+    const int ncell = tl.y;
+    const int jlo = tl.z, jhi = tl.w;
+    const int* __restrict__ cs = dc.cellstart[variant][rule];
+    const double* __restrict__ pos = dc.pos[variant][rule];
+    const double2* __restrict__ src = db.src + (rule ? dc.M : 0);
+    // first batch's loads are issued before the barrier
+    double P_next = 0.0;
+    double2 c_next = make_double2(0.0, 0.0);
+    NodeRef nr_next;
+    nr_next.no = nr_next.wt = 0.0;
+    nr_next.sp = 0;
+    if (jlo + tid < jhi) {
+      P_next = pos[jlo + tid];
+      if constexpr (FUSED) nr_next = node_fetch(dc, variant, rule, jlo + tid);
+      else c_next = src[jlo + tid];
+    }
+    // lane mapping: tiles at the sub-panel edges have few cells but many sources, so the 64 lanes of
+    // a wave are split as (cell, sub): `spl` lanes share one cell and take strided sources
+    int c2 = 64;
+    while (c2 / 2 >= ncell && c2 > 1) c2 >>= 1;  // smallest power of two >= ncell (<= 64)
+    const int spl = 64 / c2;
+    const int lane = tid & 63;
+    const int part = tid >> 6;
+    constexpr int NPART = kSpreadThreads / 64;
+    const int cell = lane / spl, sub = lane - cell * spl;
+    // sources touching cell L have floor(P_j) in [L - W/2, L + W/2): a contiguous range of the sorted list
+    int J0 = 0, J1 = 0;
+    if (cell < ncell) {
+      const int L = L0 + cell;
+      J0 = cs[L - W / 2 < 0 ? 0 : L - W / 2];
+      J1 = cs[L + W / 2 > (int)n1 ? (int)n1 : L + W / 2];
+    }
+    __syncthreads();  // ES tables staged; previous item's s_red consumed
+#ifdef SK_STAMPS
+    t1 = __builtin_amdgcn_s_memtime();
+#endif
+    double ar = 0.0, ai = 0.0;
+    for (int jb = jlo; jb < jhi; jb += kSpreadThreads) {
+      const int j = jb + tid;
+      const int nb = (jhi - jb) < kSpreadThreads ? (jhi - jb) : kSpreadThreads;
+      if (j < jhi) {
+        const double P = P_next;
+        if constexpr (FUSED) {
+          const NodeRef nr = nr_next;
+          if (j + kSpreadThreads < jhi) {  // prefetch the next batch
+            P_next = pos[j + kSpreadThreads];
+            nr_next = node_fetch(dc, variant, rule, j + kSpreadThreads);
+          }
+          const double cj = node_strength(dc, pp, nr);
+          const double u = (P - 0.5 * (double)dc.n1) * dc.delta;
+          const double2 ph = cis_turns_prod(pp.kappa, u);  // type-3 pre-phase
+          s_c[tid] = make_double2(cj * ph.x, cj * ph.y);
+        } else {
+          s_c[tid] = c_next;
+          if (j + kSpreadThreads < jhi) {  // prefetch the next batch
+            P_next = pos[j + kSpreadThreads];
+            c_next = src[j + kSpreadThreads];
+          }
+        }
+        const double tcn = P - 0.5 * W;
+        const double l0d = ceil(tcn);
+        const double y = (l0d - tcn) - 0.5;
+        const double y2 = y * y;
+        s_l0[tid] = (int)l0d - L0;
+        double* wrow = &s_w[tid * (W + 1)];
 #pragma unroll
-      for (int qq = 0; qq < W / 2; ++qq) {
-        double E, O;
-        es_pair<W>(s_poly, qq, y2, E, O);
-        wrow[qq] = fma(y, O, E);
-        wrow[W - 1 - qq] = fma(-y, O, E);
-      }
-    }
-    __syncthreads();
-#ifdef SK_STAMPS
-    if (jb == jlo) t2 = __builtin_amdgcn_s_memtime();
-#endif
-    {
-      const int j0 = (J0 > jb ? J0 : jb) - jb;
-      const int j1 = (J1 < jb + nb ? J1 : jb + nb) - jb;
-      for (int jj = j0 + part * spl + sub; jj < j1; jj += NPART * spl) {
-        const int rel = cell - s_l0[jj];
-        if (rel >= 0 && rel < W) {
-          const double wv = s_w[jj * (W + 1) + rel];
-          const double2 c = s_c[jj];
-          ar = fma(c.x, wv, ar);
-          ai = fma(c.y, wv, ai);
+        for (int qq = 0; qq < W / 2; ++qq) {
+          double E, O;
+          es_pair<W>(s_poly, qq, y2, E, O);
+          wrow[qq] = fma(y, O, E);
+          wrow[W - 1 - qq] = fma(-y, O, E);
         }
       }
+      __syncthreads();
+#ifdef SK_STAMPS
+      if (jb == jlo) t2 = __builtin_amdgcn_s_memtime();
+#endif
+      {
+        const int j0 = (J0 > jb ? J0 : jb) - jb;
+        const int j1 = (J1 < jb + nb ? J1 : jb + nb) - jb;
+        for (int jj = j0 + part * spl + sub; jj < j1; jj += NPART * spl) {
+          const int rel = cell - s_l0[jj];
+          if (rel >= 0 && rel < W) {
+            const double wv = s_w[jj * (W + 1) + rel];
+            const double2 c = s_c[jj];
+            ar = fma(c.x, wv, ar);
+            ai = fma(c.y, wv, ai);
+          }
+        }
+      }
+      __syncthreads();
+#ifdef SK_STAMPS
+      if (jb == jlo) t3 = __builtin_amdgcn_s_memtime();
+#endif
     }
+    // fixed-order reduction: sub-lanes of a cell (butterfly), then the NPART waves through LDS
+    for (int off = 1; off < spl; off <<= 1) {
+      ar += __shfl_xor(ar, off, 64);
+      ai += __shfl_xor(ai, off, 64);
+    }
+    if (sub == 0) s_red[part * 64 + cell] = make_double2(ar, ai);
     __syncthreads();
 #ifdef SK_STAMPS
-    if (jb == jlo) t3 = __builtin_amdgcn_s_memtime();
-#endif
-  }
-  // fixed-order reduction: sub-lanes of a cell (butterfly), then the NPART waves through LDS
-  for (int off = 1; off < spl; off <<= 1) {
-    ar += __shfl_xor(ar, off, 64);
-    ai += __shfl_xor(ai, off, 64);
-  }
-  if (sub == 0) s_red[part * 64 + cell] = make_double2(ar, ai);
-  __syncthreads();
-#ifdef SK_STAMPS
-  t4 = __builtin_amdgcn_s_memtime();
-  if (tid == 0 && db.stamps) {
-    unsigned long long* o = db.stamps + (size_t)blockIdx.x * 8;
-    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = (unsigned long long)(jhi - jlo); o[6] = ncell;
-    o[7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID... best effort
-  }
-#endif
-  if (part == 0 && sub == 0 && cell < ncell) {
-#pragma unroll
-    for (int pidx = 1; pidx < NPART; ++pidx) {
-      ar += s_red[pidx * 64 + cell].x;
-      ai += s_red[pidx * 64 + cell].y;
+    t4 = __builtin_amdgcn_s_memtime();
+    if (tid == 0 && db.stamps) {
+      unsigned long long* o = db.stamps + (size_t)item * 8;
+      o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = (unsigned long long)(jhi - jlo); o[6] = ncell;
+      o[7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID... best effort
     }
-    const int64_t l = (int64_t)(L0 + cell) - n1 / 2;
-    // (-1)^l centres the FFT output (index k + n2/2), so k_interp never wraps around
-    const double dcv = ((l & 1) ? -1.0 : 1.0) * dc.deconv[l < 0 ? -l : l];
-    db.fft[(int64_t)rule * n2 + (l < 0 ? l + n2 : l)] = make_double2(ar * dcv, ai * dcv);
+#endif
+    if (part == 0 && sub == 0 && cell < ncell) {
+#pragma unroll
+      for (int pidx = 1; pidx < NPART; ++pidx) {
+        ar += s_red[pidx * 64 + cell].x;
+        ai += s_red[pidx * 64 + cell].y;
+      }
+      const int64_t l = (int64_t)(L0 + cell) - n1 / 2;
+      // (-1)^l centres the FFT output (index k + n2/2), so k_interp never wraps around
+      const double dcv = ((l & 1) ? -1.0 : 1.0) * dc.deconv[l < 0 ? -l : l];
+      db.fft[(int64_t)rule * n2 + (l < 0 ? l + n2 : l)] = make_double2(ar * dcv, ai * dcv);
+    }
   }
+  // the deferred tail fit, off the critical path: by the last workgroup after its items.  FUSED: this
+  // workgroup published the state in step_state (same thread, program order).
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) resolve_tail(db.state[slot], dc);
 }
 
 // k_spread_multi: the same tile algorithm for the kHkTerms coefficient sets of the Hankel path in one
@@ -1346,8 +1438,17 @@ void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, 
   // both variants have their own work list; launch for the longer one (extra blocks zero-pad or idle)
   const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
   const unsigned padblk = nblk(2 * (dc.n2 - dc.n1), kSpreadThreads);
-  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_spread<W>, dim3(tiles + padblk), dim3(kSpreadThreads), 0, st, dc, ec, db,
-                                         slot));
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_spread<W, false>), dim3(tiles + padblk), dim3(kSpreadThreads), 0, st, dc, ec, db,
+                                         slot, 0, 0ll, 0.0, 0.0));
+}
+void launch_genspread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int mode, int t, long long n, double k0,
+                      double ks0, hipStream_t st) {
+  const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
+  const unsigned padblk = nblk(2 * (dc.n2 - dc.n1), kSpreadThreads);
+  // resident at once: 256 CUs x 4 workgroups (LDS- and VGPR-limited), items taken with stride
+  const unsigned grid = tiles + padblk < 1024u ? tiles + padblk : 1024u;
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_spread<W, true>), dim3(grid), dim3(kSpreadThreads), 0, st, dc, ec, db, t,
+                                         mode, n, k0, ks0));
 }
 void launch_hk_gen(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, int level, int slot, hipStream_t st) {
   hipLaunchKernelGGL(k_hk_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, hp, level, slot);
