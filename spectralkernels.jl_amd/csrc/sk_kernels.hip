@@ -30,20 +30,23 @@ __device__ __forceinline__ double2 cis_turns_small(double t) {
   const double q = rint(4.0 * t);          // -2 .. 2
   const double x = (2.0 * SK_PI) * fma(-0.25, q, t);  // |x| <= pi/4, the subtraction is exact
   const double z = x * x;
-  double ps = 1.58969099521155010221e-10;
-  ps = fma(ps, z, -2.50507602534068634195e-08);
-  ps = fma(ps, z, 2.75573137070700676789e-06);
-  ps = fma(ps, z, -1.98412698298579493134e-04);
-  ps = fma(ps, z, 8.33333333332248946124e-03);
-  ps = fma(ps, z, -1.66666666666666324348e-01);
+  // power-sum form with the constant as the multiplicand (v_fmac acc, const, power): a Horner step puts the
+  // constant in the addend and costs two extra v_mov_b32 (see es_weights)
+  const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z;
+  double ps = 1.58969099521155010221e-10 * z5;
+  ps = fma(-2.50507602534068634195e-08, z4, ps);
+  ps = fma(2.75573137070700676789e-06, z3, ps);
+  ps = fma(-1.98412698298579493134e-04, z2, ps);
+  ps = fma(8.33333333332248946124e-03, z, ps);
+  ps += -1.66666666666666324348e-01;
   const double sn = fma(x * z, ps, x);
-  double pc = -1.13596475577881948265e-11;
-  pc = fma(pc, z, 2.08757232129817482790e-09);
-  pc = fma(pc, z, -2.75573143513906633035e-07);
-  pc = fma(pc, z, 2.48015872894767294178e-05);
-  pc = fma(pc, z, -1.38888888888741095749e-03);
-  pc = fma(pc, z, 4.16666666666666019037e-02);
-  const double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+  double pc = -1.13596475577881948265e-11 * z5;
+  pc = fma(2.08757232129817482790e-09, z4, pc);
+  pc = fma(-2.75573143513906633035e-07, z3, pc);
+  pc = fma(2.48015872894767294178e-05, z2, pc);
+  pc = fma(-1.38888888888741095749e-03, z, pc);
+  pc += 4.16666666666666019037e-02;
+  const double cs = fma(z2, pc, fma(-0.5, z, 1.0));
   const int qi = (int)q & 3;               // rotate by q quarter turns
   const double c0 = (qi & 1) ? -sn : cs, s0 = (qi & 1) ? cs : sn;
   return (qi & 2) ? make_double2(-c0, -s0) : make_double2(c0, s0);
@@ -816,14 +819,32 @@ __device__ __forceinline__ int tap_base(double r, double r_hi, double inv_rc, do
   return (int)fmin(fmax(k0d, -(double)(n2 / 2)), (double)(n2 / 2 - W)) + n2 / 2;
 }
 
-// The W ES-kernel weights of a lag with kernel offset y (even/odd Horner pairs, LDS tables).
+// The W ES-kernel weights of a lag with kernel offset y, tables read by scalar loads (k_interp & co).
+// The even/odd polynomials are summed against precomputed powers of y^2 with the coefficient as the
+// *multiplicand*: v_fmac_f64 acc, s[coef], v[power].  Horner (E = E*y2 + coef) puts the SGPR coefficient in
+// the addend, and the compiler then copies every coefficient into a VGPR pair first (2 v_mov_b32 per step:
+// 200 of k_interp's 590 VALU instructions per wave, found with SQ_INSTS_VALU / the ISA histogram).
 template <int W>
-__device__ __forceinline__ void es_weights(const double* s_poly, double y, double (&wt)[W]) {
+__device__ __forceinline__ void es_weights(const double* poly, double y, double (&wt)[W]) {
+  constexpr int NCO = W / 2 + 1;
   const double y2 = y * y;
+  double pw[NCO];  // pw[i] = y2^i
+  pw[0] = 1.0;
+  pw[1] = y2;
+#pragma unroll
+  for (int i = 2; i < NCO; ++i) pw[i] = pw[i - 1] * y2;
 #pragma unroll
   for (int q = 0; q < W / 2; ++q) {
-    double E, O;
-    es_pair<W>(s_poly, q, y2, E, O);
+    const double* pe = poly + q * 2 * NCO;  // highest power first
+    const double* po = pe + NCO;
+    double E = pe[0] * pw[NCO - 1], O = po[0] * pw[NCO - 1];
+#pragma unroll
+    for (int i = 1; i < NCO - 1; ++i) {  // smallest terms first
+      E = fma(pe[i], pw[NCO - 1 - i], E);
+      O = fma(po[i], pw[NCO - 1 - i], O);
+    }
+    E += pe[NCO - 1];
+    O += po[NCO - 1];
     wt[q] = fma(y, O, E);
     wt[W - 1 - q] = fma(-y, O, E);
   }
@@ -870,48 +891,68 @@ __device__ __forceinline__ void interp_finish(const DevConst& dc, const double* 
   F2 = make_double2(H2.x * ph.x - H2.y * ph.y, H2.x * ph.y + H2.y * ph.x);
 }
 
-// One evaluation of the current (sub)panel at the active lags.  Per lag: read r and the confirmed
-// running sums, write the optimistic sums (other acc buffer) and the optimistic final outputs
-// ks = K-sum (src/quadrature.jl:261, src/adaptive.jl:163), errs = err-sum + 2*trunc_err
-// (src/quadrature.jl:262, src/adaptive.jl:164,194).  A lag's outputs become final when it retires;
-// until then every later evaluation overwrites them.  Per workgroup: max |I2-I1|, NaN flags and the
-// highest lag failing the convergence predicate (src/adaptive.jl:183-198, :231-233), all
-// speculative on this panel being accepted -- k_advance decides.
+// One evaluation of the current (sub)panel at the active lags, 256 lags per workgroup.  Per lag: read r and
+// the confirmed running sums, write the optimistic sums (other acc buffer) and, for lags that may retire with
+// this evaluation, the optimistic final outputs ks = K-sum (src/quadrature.jl:261, src/adaptive.jl:163),
+// errs = err-sum + 2*trunc_err (src/quadrature.jl:262, src/adaptive.jl:164,194).  Per workgroup: max |I2-I1|,
+// NaN flags and the highest lag failing the convergence predicate (src/adaptive.jl:183-198, :231-233), all
+// speculative on this panel being accepted -- the next step's prologue decides.
+// (Several chunks per workgroup with all loads issued up front -- every wave resident at once -- was measured
+// 10-30 % slower: the load, evaluate and store phases of the whole grid then line up instead of overlapping.)
 template <int W, int RAW>
 __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, DevBuffers db, int slot, long long n) {
   __shared__ double smax[4];
   __shared__ unsigned int shi[4];
-  __shared__ int sflag[2];
+  __shared__ int sflag[4][2];
   __shared__ double2 s_win[2 * kWinCap];
-  // read the needed state fields before any store so that the loads stay scalar
+  // every state field in one batch of scalar loads ahead of the first branch (read one by one behind the `done`
+  // and sanity branches they cost a dependent load + wait each: 13 serialised waits per wave in the ISA), and
+  // before any store so that the loads stay scalar
   const DevState& s = db.state[slot];
-  if (s.done) return;
-  if (!state_sane(s, db, n)) return;
+  const int done = s.done;
+  const long long sn = s.n;
   const PanelParams pp = s.pp;
   const TailScalars tail = s.tail;
   const int conf = s.conf, has_acc = s.has_acc, pc = s.pc, p_valid = s.p_valid, stack_len = s.stack_len;
   const double T2 = dc.tol * s.k0abs * 0.5;
   const long long ix1 = s.ix1, hi = s.hi;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if ((long long)blockIdx.x * blockDim.x >= hi) return;
+  // done, or not a sane state (state_sane plus NaN / range checks of the fields used below): evaluated without
+  // short-circuit so that every load above stays ahead of this one branch
+  const unsigned bad = (unsigned)(done != 0) | (unsigned)(sn != n) | (unsigned)((unsigned long long)ix1 > 1ull) |
+                       (unsigned)(hi < 0) | (unsigned)(hi > n) | (unsigned)((unsigned)conf > 1u) | (unsigned)((unsigned)pc > 1u) |
+                       (unsigned)((unsigned)stack_len > (unsigned)kStackCap) | (unsigned)((unsigned)pp.jacobi > 1u) |
+                       (unsigned)((unsigned)has_acc > 1u) | (unsigned)((unsigned)p_valid > 1u) |
+                       (unsigned)((unsigned)tail.crit > 2u) | (unsigned)(T2 != T2) | (unsigned)(pp.r_hi != pp.r_hi) |
+                       (unsigned)(pp.tau != pp.tau) | (unsigned)(pp.Cx != pp.Cx) | (unsigned)(pp.theta_scale != pp.theta_scale) |
+                       (unsigned)(pp.inv_rc != pp.inv_rc);
+  if (bad) return;
+  // buffer roles of this step, selected from kernel-argument pointers up front: indexing db.accK[conf ^ 1] at
+  // the store would be a dependent scalar load (and a stall) right where the wave wants to retire
+  const double* const cK = conf ? db.accK[1] : db.accK[0];
+  const double* const cE = conf ? db.accE[1] : db.accE[0];
+  double* const oK = conf ? db.accK[0] : db.accK[1];
+  double* const oE = conf ? db.accE[0] : db.accE[1];
+  const double* const pIn = pc ? db.P[1] : db.P[0];
+  double* const pOut = pc ? db.P[0] : db.P[1];
+  const long long blk0 = (long long)blockIdx.x * 256;  // first lag of this workgroup
+  if (blk0 >= hi) return;
+  const long long i = blk0 + threadIdx.x;
   const bool act = (i >= ix1 && i < hi);
   const int n2i = (int)dc.n2;
-  // Ablation (tools/diag/ablate.sh) showed the 2W per-lane 16-B gathers cost 11.5 of 27 us: a wave's
-  // dwordx4 load occupies the vector L1 for 16 cycles whatever the addresses.  The lags are sorted, so
-  // the taps of this workgroup's 256 lags lie in one contiguous window of the FFT output; when it is
-  // small (dense lag sets) it is staged in LDS once, coalesced, and the taps are LDS reads (4 cycles).
-  const long long ia = (long long)blockIdx.x * blockDim.x < ix1 ? ix1 : (long long)blockIdx.x * blockDim.x;
-  const long long ib = ((long long)blockIdx.x + 1) * blockDim.x > hi ? hi - 1 : ((long long)blockIdx.x + 1) * blockDim.x - 1;
+  // The lags are sorted, so the taps of the workgroup's 256 lags lie in one contiguous window of the FFT output;
+  // when it is small (dense lag sets) it is staged in LDS once, coalesced, and the taps are LDS reads instead
+  // of 2W per-lane 16-B gathers (a wave's dwordx4 load occupies the vector L1 for 16 cycles whatever the addresses).
+  const long long ia = blk0 < ix1 ? ix1 : blk0;
+  const long long ib = blk0 + 256 > hi ? hi - 1 : blk0 + 255;
   const double r_a = db.xs[ia], r_b = db.xs[ib];  // scalar loads, in flight together with the lag's own streams
   double r = 0.0, ck = 0.0, ce = 0.0;
   if (act) {
     r = db.xs[i];
     if (has_acc) {
-      ck = db.accK[conf][i];
-      ce = db.accE[conf][i];
+      ck = cK[i];
+      ce = cE[i];
     }
   }
-  if (threadIdx.x < 2) sflag[threadIdx.x] = 0;
   int wbase, wsize;
   {
     double vv, yy;
@@ -920,13 +961,12 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
   }
   const bool use_win = (wsize >= W && wsize <= kWinCap);
   if (use_win) {
-    for (int j = threadIdx.x; j < wsize; j += blockDim.x) {
+    for (int j = threadIdx.x; j < wsize; j += 256) {
       s_win[j] = db.fft[wbase + j];
       s_win[kWinCap + j] = db.fft[n2i + wbase + j];
     }
   }
   __syncthreads();
-  const int o = conf ^ 1;
   double emax = 0.0;
   int n1f = 0, n2f = 0;
   unsigned int unconv = 0u;
@@ -935,17 +975,8 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
     double v, y;
     const int base = tap_base<W>(r, pp.r_hi, pp.inv_rc, pp.tau, n2i, v, y);
     double wt[W];
-#if defined(SK_ABL) && SK_ABL == 3
-    for (int q = 0; q < W; ++q) wt[q] = y;
-#else
-    es_weights<W>(ec->poly, y, wt);  // wave-uniform addresses, loaded before any store: scalar loads
-#endif
+    es_weights<W>(ec->poly, y, wt);  // wave-uniform addresses: scalar loads
     double2 H1, H2;
-#if defined(SK_ABL) && SK_ABL == 2
-    H1 = make_double2(wt[0], wt[1]); H2 = make_double2(wt[2], wt[3]);  // ablation: no gathers
-#elif defined(SK_ABL) && SK_ABL == 3
-    H1 = make_double2(y, v); H2 = make_double2(v, y);  // ablation: no weights, no gathers
-#else
     if (use_win) {
       int off = base - wbase;
       off = off < 0 ? 0 : (off > wsize - W ? wsize - W : off);  // only ever clamps on unsorted (speculative) input
@@ -953,50 +984,40 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
     } else {
       tap_sums<W, true>(db.fft + base, db.fft + n2i + base, wt, H1, H2);
     }
-#endif
-#if defined(SK_ABL) && SK_ABL == 4
-    F1 = H1; F2 = H2;  // ablation: no Clenshaw / phase
-#else
     interp_finish(dc, ec->cheb, r, pp.Cx, v, pp.theta_scale, H1, H2, F1, F2);
-#endif
     if constexpr (RAW != SK_RAW_NONE) {
       // logw first panel (src/quadrature.jl:192-207): pass A keeps the cos sums, pass B the sin sums
       double* out = db.lw_raw + (RAW == SK_RAW_A ? 0 : 2 * n);
       out[i] = (RAW == SK_RAW_A) ? F1.x : F1.y;
       out[n + i] = (RAW == SK_RAW_A) ? F2.x : F2.y;
-      return;
-    }
-    const double scale = dc.c;  // src/quadrature.jl:250-255 (dim == 1)
-    const double I1 = (dc.derivative ? F1.y : F1.x) * scale;
-    const double I2 = (dc.derivative ? F2.y : F2.x) * scale;
-    const double e = fabs(I2 - I1);
-    emax = e;
-    n1f = isnan(I1);
-    n2f = isnan(I2);
-    const double Sk = ck + I2, Se = ce + e;
-#if defined(SK_ABL) && SK_ABL == 1
-    if (Sk == 1.2345e300) db.accK[o][i] = Sk;  // ablation: (almost) no stores
-#else
-    db.accK[o][i] = Sk;
-    db.accE[o][i] = Se;
-#endif
-    const double pk = (p_valid ? db.P[pc][i] : 0.0) + I2;
-    double te2 = 0.0;
-    if (stack_len == 0) {
-      const int crit = tail.crit;
-      const double te = (crit == SK_CRIT_PANEL) ? 0.0 : trunc_est(tail, r, dc.dim);
-      const bool conv = (crit == SK_CRIT_PANEL || te < T2) && (crit == SK_CRIT_TAILS || fabs(pk) < T2);
-      unconv = conv ? 0u : (unsigned int)(i + 1);
-      te2 = 2.0 * te;
     } else {
-      db.P[pc ^ 1][i] = pk;  // needed by the later sub-panels of this outer panel if accepted
+      const double scale = dc.c;  // src/quadrature.jl:250-255 (dim == 1)
+      const double I1 = (dc.derivative ? F1.y : F1.x) * scale;
+      const double I2 = (dc.derivative ? F2.y : F2.x) * scale;
+      const double e = fabs(I2 - I1);
+      emax = e;
+      n1f = isnan(I1);
+      n2f = isnan(I2);
+      const double Sk = ck + I2, Se = ce + e;
+      oK[i] = Sk;
+      oE[i] = Se;
+      const double pk = (p_valid ? pIn[i] : 0.0) + I2;
+      if (stack_len == 0) {
+        const int crit = tail.crit;
+        const double te = (crit == SK_CRIT_PANEL) ? 0.0 : trunc_est(tail, r, dc.dim);
+        const bool conv = (crit == SK_CRIT_PANEL || te < T2) && (crit == SK_CRIT_TAILS || fabs(pk) < T2);
+        unconv = conv ? 0u : (unsigned int)(i + 1);
+        // Optimistic final outputs.  A lag can only retire with this evaluation if it completes an outer panel
+        // (stack empty) and its own predicate holds (retirement is from the top: every retiring lag converged),
+        // so only those lags write them -- the others are rewritten by the evaluation that does retire them.
+        if (conv) {
+          db.ks[i] = Sk;
+          db.errs[i] = Se + 2.0 * te;
+        }
+      } else {
+        pOut[i] = pk;  // needed by the later sub-panels of this outer panel if accepted
+      }
     }
-#if defined(SK_ABL) && SK_ABL == 1
-    if (Se == 1.2345e300) db.ks[i] = Sk + te2;
-#else
-    db.ks[i] = Sk;
-    db.errs[i] = Se + te2;
-#endif
   }
   if constexpr (RAW != SK_RAW_NONE) return;
   // wave reductions by shuffles (same-address LDS atomics from 64 lanes serialise and were 10 us slower),
@@ -1006,26 +1027,28 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
     const unsigned int o2 = __shfl_xor(unconv, off, 64);
     unconv = o2 > unconv ? o2 : unconv;
   }
-  if (__any(n1f) && (threadIdx.x & 63) == 0) atomicOr(&sflag[0], 1);
-  if (__any(n2f) && (threadIdx.x & 63) == 0) atomicOr(&sflag[1], 1);
+  const int a1 = __any(n1f), a2 = __any(n2f);
   if ((threadIdx.x & 63) == 0) {
     smax[threadIdx.x >> 6] = emax;
     shi[threadIdx.x >> 6] = unconv;
+    sflag[threadIdx.x >> 6][0] = a1;
+    sflag[threadIdx.x >> 6][1] = a2;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     double b = smax[0];
     unsigned int h = shi[0];
-    for (int w2 = 1; w2 < (int)(blockDim.x >> 6); ++w2) {
+    int f = 0;
+    for (int w2 = 0; w2 < 4; ++w2) {
       b = fmax(b, smax[w2]);
       h = shi[w2] > h ? shi[w2] : h;
+      f |= (sflag[w2][0] ? 1 : 0) | (sflag[w2][1] ? 2 : 0);
     }
-    // 64-way spread atomics (about 60 arrivals per address for 10^6 lags), reduced by the next k_gen
+    // 64-way spread atomics (about 60 arrivals per address for 10^6 lags), reduced by the next step's prologue
     Reductions& rd = db.red[slot];
     const int a = blockIdx.x & 63;
     if (b > 0.0) atomicMax(&rd.max_bits[a], (unsigned long long)__double_as_longlong(b));
     if (h) atomicMax(&rd.hi[a], h);
-    const int f = sflag[0] | (sflag[1] << 1);
     if (f) atomicOr(&rd.nan, f);
   }
 }
@@ -1058,18 +1081,18 @@ __device__ __forceinline__ void lag_epilogue(const DevConst& dc, const DevBuffer
   db.accK[o][i] = Sk;
   db.accE[o][i] = Se;
   const double pk = (es.p_valid ? db.P[es.pc][i] : 0.0) + I2;
-  double te2 = 0.0;
   if (es.stack_len == 0) {
     const int crit = es.tail.crit;
     const double te = (crit == SK_CRIT_PANEL) ? 0.0 : trunc_est(es.tail, r, dc.dim);
     const bool conv = (crit == SK_CRIT_PANEL || te < es.T2) && (crit == SK_CRIT_TAILS || fabs(pk) < es.T2);
     unconv = conv ? 0u : (unsigned int)(i + 1);
-    te2 = 2.0 * te;
+    if (conv) {  // only a converged lag can retire with this evaluation (see k_interp)
+      db.ks[i] = Sk;
+      db.errs[i] = Se + 2.0 * te;
+    }
   } else {
     db.P[es.pc ^ 1][i] = pk;
   }
-  db.ks[i] = Sk;
-  db.errs[i] = Se + te2;
 }
 // workgroup (256 threads) reduction of the per-lag results into the 64 spread slots of this step
 __device__ __forceinline__ void block_reduce(const DevBuffers& db, int slot, double emax, int n1f, int n2f,
