@@ -176,10 +176,10 @@ def main():
     dom = max(acc, key=lambda k: acc[k]["total_ms"])
     # algorithmic bytes per launch: interp/accum per active lag, gen/spread per panel
     M = cfg.quadspec[0] * cfg.quadspec[1]
-    # interp per active lag: read r (8) + confirmed sums (16, not on the very first panel) and write the
-    # optimistic sums (16) and the outputs (16)  -> 56 B, 40 B on the first panel (Kernels)
-    n_first = st["n_unique"] - (1 if rs[0] == 0.0 else 0)
-    interp_bytes_total = 10 * (56.0 * st["sum_active"] - 16.0 * n_first)  # over the 10 profiled calls
+    # interp per active lag and evaluation: read r (8) + confirmed sums (16, not on the very first panel), write the
+    # optimistic sums (16); the final outputs (16) once per lag, when it retires  -> 40 B x sum_active per call
+    # (40*sum_active - 16*n_first + 16*n_first; DESIGN.md, Kernels)
+    interp_bytes_total = 10 * 40.0 * st["sum_active"]  # over the 10 profiled calls
     rl = {}
     for k, v in acc.items():
         if v["launches"] == 0:
@@ -191,7 +191,9 @@ def main():
         elif k == "gen":
             b = 48.0 * M + 48.0 * M  # read node + weight of both rules (M + 2M) x (8 + 8), write 3M complex strengths
         elif k == "spread":
-            b = 48.0 * M + 24.0 * M + 16.0 * items  # read 3M complex strengths + positions; write two complex grids
+            # read 3M complex strengths (separate k_gen) or 3M nodes + weights (fused launch) and 3M positions;
+            # write two complex grids
+            b = 48.0 * M + 24.0 * M + 16.0 * items
         elif k == "fft":
             b = 2 * 16.0 * items  # read + write both grids once
         else:
