@@ -8,7 +8,7 @@
 # exercised through its line-by-line ctypes mirror spectralkernels.jl_amd/api.py.)
 module SpectralKernelsHIP
 
-export AdaptiveKernelConfig, kernel_values, compute_k0, MaternSDF, ExponentialSDF, GaussianSDF
+export AdaptiveKernelConfig, kernel_values, kernel_values_pairs, build_dense_cov_matrix, compute_k0, MaternSDF, ExponentialSDF, GaussianSDF
 
 const LIB = get(ENV, "SPECTRALKERNELS_HIP_LIB",
                 joinpath(@__DIR__, "..", "libspectralkernels_hip.so"))
@@ -115,6 +115,46 @@ function kernel_values(cfg::AdaptiveKernelConfig, xs::AbstractVector{Float64};
                  param_derivative ? 1 : 0, vals, errs))
   end
   (vals, errs)
+end
+
+# Lags of point pairs formed on the device -- what gen_kernel_setup / gen_kernel do with
+# `norm(warp_pts[j] - warp_pts[k])` (src/model.jl:64-65,76).  pts: vector of points (numbers or static vectors),
+# pairs: vector of 1-based index tuples as in sm.kernel_index_pairs.
+function kernel_values_pairs(cfg::AdaptiveKernelConfig, pts::AbstractVector, pairs::AbstractVector{<:Tuple{Integer,Integer}};
+                             k0=nothing, param_derivative=false)
+  pdim = length(first(pts))
+  p    = Matrix{Float64}(undef, pdim, length(pts))            # column-major pdim x npts == row-major npts x pdim
+  for (j, pt) in enumerate(pts), d in 1:pdim
+    p[d, j] = pt[d]
+  end
+  ix   = Matrix{Int64}(undef, 2, length(pairs))
+  for (e, (j, k)) in enumerate(pairs)
+    ix[1, e] = j - 1; ix[2, e] = k - 1
+  end
+  vals = Vector{Float64}(undef, length(pairs))
+  errs = Vector{Float64}(undef, length(pairs))
+  GC.@preserve cfg begin
+    _check(ccall((:sk_kernel_values_pairs, LIB), Cint,
+                 (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Cint, Ptr{Int64}, Csize_t, Cdouble, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
+                 cfg.handle, p, length(pts), pdim, ix, length(pairs), isnothing(k0) ? 0.0 : Float64(k0),
+                 isnothing(k0) ? 0 : 1, param_derivative ? 1 : 0, vals, errs))
+  end
+  (vals, errs)
+end
+
+# build_dense_cov_matrix(cfg, pts) -- src/utils.jl:41-64
+function build_dense_cov_matrix(cfg::AdaptiveKernelConfig, pts::AbstractVector)
+  pdim = length(first(pts))
+  p    = Matrix{Float64}(undef, pdim, length(pts))
+  for (j, pt) in enumerate(pts), d in 1:pdim
+    p[d, j] = pt[d]
+  end
+  out = Matrix{Float64}(undef, length(pts), length(pts))       # symmetric: layout does not matter
+  GC.@preserve cfg begin
+    _check(ccall((:sk_dense_cov_matrix, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Cint, Ptr{Cdouble}),
+                 cfg.handle, p, length(pts), pdim, out))
+  end
+  out
 end
 
 end # module
