@@ -1464,14 +1464,29 @@ void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, 
   SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_spread<W, false>), dim3(tiles + padblk), dim3(kSpreadThreads), 0, st, dc, ec, db,
                                          slot, 0, 0ll, 0.0, 0.0));
 }
+// workgroups of the fused kernel that are resident at once (so that the state prologue is paid once per slot)
+template <int W>
+static unsigned genspread_resident() {
+  static unsigned cached = 0;
+  if (!cached) {
+    int per_cu = 0, dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_spread<W, true>, kSpreadThreads, 0) != hipSuccess || per_cu < 1)
+      per_cu = 3;
+    cached = (unsigned)(per_cu * cus);
+  }
+  return cached;
+}
 void launch_genspread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int mode, int t, long long n, double k0,
                       double ks0, hipStream_t st) {
   const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
   const unsigned padblk = nblk(2 * (dc.n2 - dc.n1), kSpreadThreads);
-  // resident at once: 256 CUs x 4 workgroups (LDS- and VGPR-limited), items taken with stride
-  const unsigned grid = tiles + padblk < 1024u ? tiles + padblk : 1024u;
-  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_spread<W, true>), dim3(grid), dim3(kSpreadThreads), 0, st, dc, ec, db, t,
-                                         mode, n, k0, ks0));
+  SK_DISPATCH_W(dc.w, {
+    const unsigned res = genspread_resident<W>();
+    const unsigned grid = tiles + padblk < res ? tiles + padblk : res;  // items are taken with stride gridDim.x
+    hipLaunchKernelGGL((k_spread<W, true>), dim3(grid), dim3(kSpreadThreads), 0, st, dc, ec, db, t, mode, n, k0, ks0);
+  });
 }
 void launch_hk_gen(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, int level, int slot, hipStream_t st) {
   hipLaunchKernelGGL(k_hk_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, hp, level, slot);
