@@ -695,6 +695,8 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     dc.n2 = 2 * dc.n1;
   }
   dc.delta = 2.0 / (double)(dc.n1 - dc.w);
+  dc.tau_fac = (double)dc.n2 / (double)(dc.n1 - dc.w);
+  dc.theta_fac = 2.0 * M_PI / (double)(dc.n1 - dc.w);
   dc.theta_max = 1.001 * (M_PI / 2.0) * (double)cfg->M / (double)(dc.n1 - dc.w);
   build_es_tables(dc.w, dc.n1, dc.n2, dc.theta_max, cfg->tab);
   dc.nco = cfg->tab.nco;

@@ -41,6 +41,7 @@ struct DevConst {
   int64_t n1, n2;
   int w, nco, ncheb;
   double theta_max, delta;  // delta = 2/(n1-w): grid spacing in u = (omega-Cx)/X
+  double tau_fac, theta_fac;  // n2/(n1-w), 2 pi/(n1-w): panel-independent factors of PanelParams::tau / theta_scale
   // tables (device pointers)
   const double* leg_no1; const double* leg_wt1; const double* leg_no2; const double* leg_wt2;
   const double* jac_no1; const double* jac_wt1; const double* jac_no2; const double* jac_wt2;
@@ -86,6 +87,7 @@ struct DevState {
   double k0abs;         // |k0|
   double ks0;           // value stored at x == 0
   long long n, ix1, hi, hi_prev;  // active lags are [ix1, hi)
+  long long rhi_for;    // value of hi for which pp.r_hi / pp.inv_rc were loaded (-1: none)
   TailScalars tail;     // of the current outer panel
   // confirmed running sums live in acc buffer `conf` (valid iff has_acc); every evaluation writes
   // the optimistic sums into the other buffer, an accepted panel flips `conf`.  P (the current

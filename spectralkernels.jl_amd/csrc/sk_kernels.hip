@@ -98,6 +98,19 @@ __device__ __forceinline__ double sdf_deriv_dev(int kind, const double* prm, dou
 
 // ------------------------------------------------------------------ scalar state logic
 
+// Largest active lag xs[hi-1] and 2/r_hi, cached in the state: the transition runs in one lane at the head of
+// every step, where a dependent global load (and a division) is ~1 us of exposed latency; hi only changes when
+// lags retire.
+__device__ __forceinline__ double current_rhi(DevState& s, const double* xs) {
+  if (s.rhi_for != s.hi) {
+    const double r_hi = xs[s.hi - 1];
+    s.pp.r_hi = r_hi;
+    s.pp.inv_rc = 2.0 / r_hi;
+    s.rhi_for = s.hi;
+  }
+  return s.pp.r_hi;
+}
+
 __device__ void set_panel(DevState& s, const DevConst& dc, const double* xs, double pa, double pb) {
   PanelParams& pp = s.pp;
   pp.pa = pa;
@@ -108,13 +121,11 @@ __device__ void set_panel(DevState& s, const DevConst& dc, const double* xs, dou
   }
   pp.Cx = 0.5 * (pa + pb);
   pp.X = 0.5 * (pb - pa);
-  double r_hi = xs[s.hi - 1];
-  pp.r_hi = r_hi;
-  pp.inv_rc = 2.0 / r_hi;
-  double xr = pp.X * r_hi;
+  const double r_hi = current_rhi(s, xs);
+  const double xr = pp.X * r_hi;
   pp.kappa = 0.5 * xr;
-  pp.tau = xr * (double)dc.n2 / (double)(dc.n1 - dc.w);
-  pp.theta_scale = 2.0 * SK_PI * xr / (double)(dc.n1 - dc.w);
+  pp.tau = xr * dc.tau_fac;            // n2 / (n1 - w)
+  pp.theta_scale = xr * dc.theta_fac;  // 2 pi / (n1 - w)
   pp.jacobi = (dc.p != 0.0 && pa == 0.0) ? 1 : 0;
 }
 
@@ -160,7 +171,7 @@ __device__ void tail_scalars(DevState& s, const DevConst& dc) {
 __device__ void setup_outer(DevState& s, const DevConst& dc, const double* xs) {
   if (s.hi > s.ix1) {
     double a = s.b;
-    double b = s.b + (double)dc.M / (2.0 * xs[s.hi - 1]);
+    double b = s.b + (double)dc.M / (2.0 * current_rhi(s, xs));
     s.a = a;
     s.b = b;
     s.n_outer += 1;
@@ -203,6 +214,7 @@ __device__ __forceinline__ bool step_accept(const DevState& s, double tol) {
 // Initial state (src/adaptive.jl:122-146): everything active, first outer panel.
 __device__ void init_state(DevState& s, const DevConst& dc, const DevBuffers& db, long long n, double k0, double ks0) {
   memset(&s, 0, sizeof(s));
+  s.rhi_for = -1;
   s.n = n;
   s.k0abs = fabs(k0);
   s.ks0 = ks0;
@@ -288,6 +300,14 @@ __device__ void step_state(DevState& sh, const DevConst& dc, const DevBuffers& d
   __shared__ double r_max;
   __shared__ unsigned int r_hi;
   __shared__ int r_nan;
+  static_assert(sizeof(DevState) % 4 == 0, "DevState is copied dword-wise");
+  if (mode != SK_MODE_INIT) {
+    // the previous state, one dword per lane: in flight together with the reduction slots below (a struct copy
+    // by one thread is a second, serial round trip)
+    const unsigned* src = reinterpret_cast<const unsigned*>(&db.state[(mode == SK_MODE_TRANSITION ? t - 1 : t) & 1]);
+    unsigned* dst = reinterpret_cast<unsigned*>(&sh);
+    for (unsigned q = threadIdx.x; q < sizeof(DevState) / 4; q += blockDim.x) dst[q] = src[q];
+  }
   if (mode == SK_MODE_TRANSITION && threadIdx.x < 64) {
     const Reductions& rd = db.red[(t - 1) & 1];
     double m = __longlong_as_double((long long)rd.max_bits[threadIdx.x]);
@@ -311,9 +331,8 @@ __device__ void step_state(DevState& sh, const DevConst& dc, const DevBuffers& d
         db.ks[0] = ks0;
         db.errs[0] = __builtin_nan("");
       }
-    } else {
-      sh = db.state[(mode == SK_MODE_TRANSITION ? t - 1 : t) & 1];
-      if (mode == SK_MODE_TRANSITION) transition(sh, dc, db, r_max, r_hi, r_nan, lead);
+    } else if (mode == SK_MODE_TRANSITION) {
+      transition(sh, dc, db, r_max, r_hi, r_nan, lead);
     }
     if (!sh.done && !state_sane(sh, db, n)) sh.done = -SK_EHIP;
     if (lead && (mode != SK_MODE_ASIS || sh.done == -SK_EHIP)) db.state[t & 1] = sh;
@@ -513,6 +532,9 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
   __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
   __shared__ DevState sh;
   const int slot = FUSED ? (slot_or_t & 1) : slot_or_t;
+#ifdef SK_STAMPS
+  const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
   if constexpr (FUSED) {
     step_state(sh, dc, db, mode, slot_or_t, n, k0, ks0, blockIdx.x == gridDim.x - 1);
     if (mode == SK_MODE_INIT && db.check_input) check_input_lags(db, n);
@@ -537,6 +559,10 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
     pp.kappa = uni(sh.pp.kappa);
     pp.jacobi = variant;
   }
+#ifdef SK_STAMPS
+  const unsigned long long tk1 = __builtin_amdgcn_s_memtime();
+  int nitems = 0;
+#endif
   stage_es_tables<W>(ec, s_poly, nullptr);  // made visible by the first barrier of the tile loop
   // Work items: the variant's tiles (heaviest first), then the zero padding of the FFT input.  The separate
   // kernel is launched with one workgroup per item; the fused one with a grid that is resident at once, so
@@ -556,6 +582,7 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
     }
 #ifdef SK_STAMPS
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    ++nitems;
 #endif
     const int4 tl = dc.tiles[variant][item];  // {rule<<30 | first cell, cells, first source, end source}
     const int rule = (tl.x >> 30) & 1;
@@ -685,6 +712,12 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
   // the deferred tail fit, off the critical path: by the last workgroup after its items.  FUSED: this
   // workgroup published the state in step_state (same thread, program order).
   if (blockIdx.x == gridDim.x - 1 && tid == 0) resolve_tail(db.state[slot], dc);
+#ifdef SK_STAMPS
+  if (tid == 0 && db.stamps && blockIdx.x < 2000) {
+    unsigned long long* o = db.stamps + (size_t)(6000 + blockIdx.x) * 8;
+    o[0] = tk0; o[1] = tk1; o[2] = __builtin_amdgcn_s_memtime(); o[3] = (unsigned long long)nitems;
+  }
+#endif
 }
 
 // k_spread_multi: the same tile algorithm for the kHkTerms coefficient sets of the Hankel path in one
