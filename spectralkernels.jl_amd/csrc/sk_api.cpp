@@ -696,6 +696,12 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   }
   dc.delta = 2.0 / (double)(dc.n1 - dc.w);
   dc.tau_fac = (double)dc.n2 / (double)(dc.n1 - dc.w);
+  dc.log2m = -1;
+  if ((m & (m - 1)) == 0 && 2 * cfg->M * 2 < (int64_t)1 << 31) {
+    dc.log2m = 0;
+    while (((int64_t)1 << dc.log2m) < m) ++dc.log2m;
+  }
+  dc.inv_k = ((k & (k - 1)) == 0) ? 1.0 / (double)k : 0.0;
   dc.theta_fac = 2.0 * M_PI / (double)(dc.n1 - dc.w);
   dc.theta_max = 1.001 * (M_PI / 2.0) * (double)cfg->M / (double)(dc.n1 - dc.w);
   build_es_tables(dc.w, dc.n1, dc.n2, dc.theta_max, cfg->tab);

@@ -434,7 +434,7 @@ struct NodeRef { double no, wt; int sp; };
 __device__ __forceinline__ NodeRef node_fetch(const DevConst& dc, int jacobi, int rule, int j) {
   const int mr = (int)(rule ? 2 * dc.m : dc.m);
   NodeRef r;
-  r.sp = j / mr;
+  r.sp = dc.log2m >= 0 ? (j >> (dc.log2m + rule)) : j / mr;  // m a power of two (the default quadspec): no division
   const int q = j - r.sp * mr;
   if (jacobi && r.sp == 0) {
     r.no = (rule ? dc.jac_no2 : dc.jac_no1)[q];
@@ -448,8 +448,11 @@ __device__ __forceinline__ NodeRef node_fetch(const DevConst& dc, int jacobi, in
 __device__ __forceinline__ double node_strength(const DevConst& dc, const PanelParams& pp, const NodeRef& nr) {
   const int sp = nr.sp;
   const double pa = pp.pa, pb = pp.pb;
-  const double sa = (sp == 0) ? pa : pa + (pb - pa) * ((double)sp / (double)dc.k);
-  const double sb = (sp + 1 == dc.k) ? pb : pa + (pb - pa) * ((double)(sp + 1) / (double)dc.k);
+  // s/k: for k a power of two the product with the exact reciprocal is the same double as the quotient
+  const double f0 = dc.inv_k > 0.0 ? (double)sp * dc.inv_k : (double)sp / (double)dc.k;
+  const double f1 = dc.inv_k > 0.0 ? (double)(sp + 1) * dc.inv_k : (double)(sp + 1) / (double)dc.k;
+  const double sa = (sp == 0) ? pa : pa + (pb - pa) * f0;
+  const double sb = (sp + 1 == dc.k) ? pb : pa + (pb - pa) * f1;
   const double bmad2 = 0.5 * (sb - sa), bpad2 = 0.5 * (sb + sa);
   const double w = bmad2 * nr.no + bpad2;
   double wq;
