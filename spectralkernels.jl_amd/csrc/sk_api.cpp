@@ -704,6 +704,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   dc.inv_k = ((k & (k - 1)) == 0) ? 1.0 / (double)k : 0.0;
   dc.theta_fac = 2.0 * M_PI / (double)(dc.n1 - dc.w);
   dc.theta_max = 1.001 * (M_PI / 2.0) * (double)cfg->M / (double)(dc.n1 - dc.w);
+  dc.inv_theta_max = 1.0 / dc.theta_max;
   build_es_tables(dc.w, dc.n1, dc.n2, dc.theta_max, cfg->tab);
   dc.nco = cfg->tab.nco;
   dc.ncheb = cfg->tab.ncheb;

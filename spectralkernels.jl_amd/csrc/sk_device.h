@@ -43,6 +43,7 @@ struct DevConst {
   double theta_max, delta;  // delta = 2/(n1-w): grid spacing in u = (omega-Cx)/X
   int log2m;           // log2(m) if m is a power of two, else -1
   double inv_k;        // 1/k if k is a power of two (exact), else 0
+  double inv_theta_max;
   double tau_fac, theta_fac;  // n2/(n1-w), 2 pi/(n1-w): panel-independent factors of PanelParams::tau / theta_scale
   // tables (device pointers)
   const double* leg_no1; const double* leg_wt1; const double* leg_no2; const double* leg_wt2;

@@ -910,7 +910,7 @@ __device__ __forceinline__ void tap_sums(const double2* taps1, const double2* ta
 __device__ __forceinline__ void interp_finish(const DevConst& dc, const double* s_cheb, double r, double Cx, double v,
                                               double theta_scale, double2 H1, double2 H2, double2& F1, double2& F2) {
   // 1/phi_hat(theta) by Clenshaw in s = 2 (theta/theta_max)^2 - 1 (LDS broadcast coefficient reads)
-  const double th = theta_scale * v / dc.theta_max;
+  const double th = (theta_scale * dc.inv_theta_max) * v;  // uniform factor first: no per-lane division
   double sarg = 2.0 * th * th - 1.0;
   sarg = sarg > 1.0 ? 1.0 : sarg;
   double b1 = 0.0, b2 = 0.0;
