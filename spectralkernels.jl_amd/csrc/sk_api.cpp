@@ -69,7 +69,7 @@ struct sk_config {
   DevBuffers db;
   std::vector<void*> owned;  // device allocations freed at destroy
   rocfft_plan plan = nullptr;
-  rocfft_plan plan_hk = nullptr;   // batch 2*kHkTerms, Hankel path
+  rocfft_plan plan_hk = nullptr;   // batch 2*hk_terms(w), Hankel path
   void* fft_work_hk = nullptr;
   rocfft_execution_info info_hk = nullptr;
   double hk_a[kHkTerms], hk_a2[kHkTerms];  // a_k(nu) of the main order and of dim/2 (logw pass B)
@@ -404,6 +404,16 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       const double r_hi = hs->pp.r_hi, pb = hs->pp.pb;
       int L = 0;
       while (L < kHkMaxLevels - 1 && kHkZ0 * std::pow(kHkBeta, L + 1) / (2.0 * M_PI * r_hi) < pb) ++L;
+      // level planning with the lag counts k_advance published: a level (and everything inside it) with at most
+      // kHkNodes lags becomes the innermost one and is summed directly at those lags
+      for (int l = 0; l <= L; ++l)
+        if (cfg->h_status->lvl_cnt[l] <= kHkNodes) {
+          L = l;
+          hp.direct_inner = 1;
+          hp.inner_lo = hs->ix1;
+          hp.inner_cnt = cfg->h_status->lvl_cnt[l];
+          break;
+        }
       hp.L = L;
       for (int l = 0; l <= L; ++l) {
         hp.edge[l] = r_hi / std::pow(kHkBeta, l);
@@ -798,7 +808,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     // Hankel path: batched plan for the K asymptotic terms x 2 rules, buffers, a_k(nu)
     size_t len2[1] = {(size_t)dc.n2};
     if (rocfft_plan_create(&cfg->plan_hk, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
-                           rocfft_precision_double, 1, len2, 2 * kHkTerms, nullptr) != rocfft_status_success) {
+                           rocfft_precision_double, 1, len2, 2 * hk_terms(dc.w), nullptr) != rocfft_status_success) {
       sk_config_destroy(cfg);
       return fail(SK_EHIP, "rocfft_plan_create (Hankel batch) failed");
     }

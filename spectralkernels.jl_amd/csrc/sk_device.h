@@ -11,7 +11,10 @@ constexpr int kMaxCheb = 24;
 constexpr int kStackCap = 5000;  // src/quadrature.jl:7
 constexpr int kTraceCap = 4096;
 // nonuniform fast Hankel transform (dim >= 2): level-split asymptotic expansion
-constexpr int kHkTerms = 16;     // K terms of the Hankel asymptotic series (valid for z >= kHkZ0)
+constexpr int kHkTerms = 16;     // most terms of the Hankel asymptotic series (valid for z >= kHkZ0)
+// Terms actually used with kernel width w: the NUFFT error target is ~10^-(w-1), and the k-th term of the series at
+// z0 = 24 is 5e-3, 1e-4, 5e-6, 3e-7, 3e-8, 3e-9, 4e-10, 6e-11, 9e-12, 2e-12, 4e-13, 8e-14, 2e-14, 6e-15, 2e-15, 5e-16.
+__host__ __device__ constexpr int hk_terms(int w) { return w <= 6 ? 4 : w <= 8 ? 6 : w <= 10 ? 8 : w <= 12 ? 10 : w <= 14 ? 13 : 16; }
 constexpr int kHkNodes = 160;    // Chebyshev nodes of the near-field interpolant per lag level
 constexpr int kHkSplit = 16;     // workgroups sharing one near-field node sum
 constexpr int kHkMaxLevels = 12; // lag levels (ratio kHkBeta) incl. the innermost near-only one
@@ -27,6 +30,10 @@ struct HankelPlan {
   double edge[kHkMaxLevels + 2];  // edge[0] = r_hi (inclusive top), edge[L+1] = 0
   double om[kHkMaxLevels + 1];    // far/near source threshold per level (om[L] = +inf)
   double a[kHkTerms];          // asymptotic coefficients a_k(nu)
+  // innermost level with at most kHkNodes lags: its (near-only) sums are taken directly at those lags
+  // [inner_lo, inner_lo + inner_cnt) instead of at Chebyshev nodes
+  int direct_inner;
+  long long inner_lo, inner_cnt;
 };
 
 // Per-config constants, passed to kernels by value.
@@ -128,6 +135,8 @@ struct Reductions {
 struct HostStatus {
   DevState state;
   int flags[2];       // k_check_sorted: [0] not strictly increasing, [1] negative or NaN lag
+  // Hankel path: number of active lags with r <= r_hi / kHkBeta^l, l = 0..kHkMaxLevels (level planning on the host)
+  long long lvl_cnt[kHkMaxLevels + 1];
   unsigned int seq;
 };
 

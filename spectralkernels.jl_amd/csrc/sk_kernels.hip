@@ -367,6 +367,18 @@ __global__ void __launch_bounds__(64) k_advance(DevConst dc, DevBuffers db, int 
                                                  double ks0, unsigned int seq) {
   __shared__ DevState sh;
   step_state(sh, dc, db, mode, t, n, k0, ks0, blockIdx.x == 0);
+  if (dc.dim > 1 && !sh.done && threadIdx.x <= kHkMaxLevels) {
+    // lags per level edge for the Hankel path's level planning: first active index with xs > r_hi / beta^l
+    double edge = sh.pp.r_hi;
+    for (int q = 0; q < (int)threadIdx.x; ++q) edge /= kHkBeta;
+    long long lo = sh.ix1, hi = sh.hi;  // xs[lo..hi) sorted ascending
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (db.xs[mid] <= edge) lo = mid + 1; else hi = mid;
+    }
+    db.host_status->lvl_cnt[threadIdx.x] = lo - sh.ix1;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     HostStatus* hs = db.host_status;
     hs->state = sh;
@@ -728,7 +740,7 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
 // Term k reads db.hk_src + k*3M and writes db.hk_fft + k*2*n2.
 template <int W>
 __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, const EsConst* ec, DevBuffers db, int slot) {
-  constexpr int NT = kHkTerms;
+  constexpr int NT = hk_terms(W);
   __shared__ double s_w[kSpreadThreads * (W + 1)];
   __shared__ double2 s_c[kSpreadThreads];
   __shared__ int s_l0[kSpreadThreads];
@@ -1304,8 +1316,9 @@ __global__ void __launch_bounds__(256) k_hk_gen(DevConst dc, DevBuffers db, Hank
   const double2 cw = db.src[jg];  // (c_j, w_j) from k_gen
   const double om = hp.om[level];
   double2* out = db.hk_src + jg;
+  const int nterms = hk_terms(dc.w);
   if (!(cw.y >= om)) {
-    for (int k = 0; k < kHkTerms; ++k) out[(int64_t)k * 3 * M] = make_double2(0.0, 0.0);
+    for (int k = 0; k < nterms; ++k) out[(int64_t)k * 3 * M] = make_double2(0.0, 0.0);
     return;
   }
   const double P = dc.pos[pp.jacobi][rule][j];
@@ -1313,7 +1326,7 @@ __global__ void __launch_bounds__(256) k_hk_gen(DevConst dc, DevBuffers db, Hank
   const double2 ph = cis_turns_prod(pp.kappa, u);
   const double q = om / cw.y;       // (w/om)^-1 in (0, 1]
   double sc = cw.x * sqrt(q);       // c (w/om)^-(k+1/2), k = 0
-  for (int k = 0; k < kHkTerms; ++k) {
+  for (int k = 0; k < nterms; ++k) {
     out[(int64_t)k * 3 * M] = make_double2(sc * ph.x, sc * ph.y);
     sc *= q;
   }
@@ -1330,7 +1343,14 @@ __global__ void __launch_bounds__(256) k_hk_near(DevConst dc, DevBuffers db, Han
   const int level = bid / (2 * kHkNodes);
   const double hi_r = hp.edge[level], lo_r = hp.edge[level + 1];
   const double half = 0.5 * (hi_r - lo_r), mid = 0.5 * (hi_r + lo_r);
-  const double r = mid + half * cospi((node + 0.5) / (double)kHkNodes);
+  double r = mid + half * cospi((node + 0.5) / (double)kHkNodes);
+  if (hp.direct_inner && level == hp.L) {  // few lags: the sums are taken at the lags themselves
+    if (node >= hp.inner_cnt) {
+      if (threadIdx.x == 0) db.hk_nodes[(((int64_t)level * 2 + rule) * kHkNodes + node) * kHkSplit + split] = 0.0;
+      return;
+    }
+    r = db.xs[hp.inner_lo + node];
+  }
   const double om = hp.om[level];
   const int64_t M = dc.M, cnt = rule ? 2 * M : M;
   const double2* __restrict__ src = db.src + (rule ? M : 0);
@@ -1353,12 +1373,16 @@ __global__ void __launch_bounds__(256) k_hk_near(DevConst dc, DevBuffers db, Han
 }
 
 // node values -> Chebyshev coefficients (first-kind nodes): one workgroup per (level, rule)
-__global__ void __launch_bounds__(kHkNodes) k_hk_cheb(DevBuffers db) {
+__global__ void __launch_bounds__(kHkNodes) k_hk_cheb(DevBuffers db, int direct_level) {
   __shared__ double f[kHkNodes];
   const double* in = db.hk_nodes + ((int64_t)blockIdx.x * kHkNodes + threadIdx.x) * kHkSplit;
   double fs = 0.0;
   for (int q = 0; q < kHkSplit; ++q) fs += in[q];
   f[threadIdx.x] = fs;
+  if ((int)(blockIdx.x >> 1) == direct_level) {  // values at the lags themselves: no transform
+    db.hk_cheb[(int64_t)blockIdx.x * kHkNodes + threadIdx.x] = fs;
+    return;
+  }
   __syncthreads();
   const int mth = threadIdx.x;
   double acc = 0.0;
@@ -1391,8 +1415,13 @@ __global__ void __launch_bounds__(256) k_hk_interp(DevConst dc, const EsConst* e
   unsigned int unconv = 0u;
   if (act) {
     double I12[2] = {0.0, 0.0};
-    // ---- near part: Chebyshev interpolant of the level's lag interval
-    {
+    // ---- near part: Chebyshev interpolant of the level's lag interval (or the sums taken at the lags themselves)
+    if (hp.direct_inner && level == hp.L) {
+      const long long q = i - hp.inner_lo;
+      const bool ok = q >= 0 && q < hp.inner_cnt;
+      I12[0] = ok ? s_cheb[0][q] : __builtin_nan("");
+      I12[1] = ok ? s_cheb[1][q] : __builtin_nan("");
+    } else {
       const double hi_r = hp.edge[level], lo_r = hp.edge[level + 1];
       const double xx = (r - 0.5 * (hi_r + lo_r)) / (0.5 * (hi_r - lo_r));
       for (int rule = 0; rule < 2; ++rule) {
@@ -1415,7 +1444,7 @@ __global__ void __launch_bounds__(256) k_hk_interp(DevConst dc, const EsConst* e
       const double izr = 1.0 / zr;
       double sck = sqrt(izr);  // (2 pi om r)^-(k+1/2), k = 0
       double a1r = 0, a1i = 0, a2r = 0, a2i = 0;  // sum_k i^k a_k sck H_k for both rules
-      for (int k = 0; k < kHkTerms; ++k) {
+      for (int k = 0; k < hk_terms(W); ++k) {
         const double2* g1 = db.hk_fft + ((int64_t)k * 2) * n2i + base;
         const double2* g2 = g1 + n2i;
         double2 H1, H2;
@@ -1535,7 +1564,7 @@ void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& d
 }
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st) {
   hipLaunchKernelGGL(k_hk_near, dim3((unsigned)((hp.L + 1) * 2 * kHkNodes * kHkSplit)), dim3(256), 0, st, dc, db, hp);
-  hipLaunchKernelGGL(k_hk_cheb, dim3((unsigned)((hp.L + 1) * 2)), dim3(kHkNodes), 0, st, db);
+  hipLaunchKernelGGL(k_hk_cheb, dim3((unsigned)((hp.L + 1) * 2)), dim3(kHkNodes), 0, st, db, hp.direct_inner ? hp.L : -1);
 }
 void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HankelPlan& hp, int level, int slot,
                       long long n, int raw, hipStream_t st) {
