@@ -1395,6 +1395,8 @@ template <int W>
 __global__ void __launch_bounds__(256) k_hk_interp(DevConst dc, const EsConst* ec, DevBuffers db, HankelPlan hp, int level,
                                                    int slot, long long n, int raw) {
   __shared__ double s_cheb[2][kHkNodes];
+  __shared__ double2 s_hwin[2 * kWinCap];  // FFT-output window of one term (both rules), as in k_interp
+  __shared__ int s_bmin[4], s_bmax[4];
   const DevState& s = db.state[slot];
   if (s.done) return;
   if (!state_sane(s, db, n)) return;
@@ -1413,6 +1415,77 @@ __global__ void __launch_bounds__(256) k_hk_interp(DevConst dc, const EsConst* e
   double emax = 0.0;
   int n1f = 0, n2f = 0;
   unsigned int unconv = 0u;
+  // ---- far part (levels below L only): K type-3 NUFFT grids, tap windows staged in LDS term by term
+  double far1 = 0.0, far2 = 0.0;
+  if (level < hp.L) {  // workgroup-uniform
+    double v = 0.0, y = 0.0;
+    int base = 0;
+    if (act) base = tap_base<W>(r, pp.r_hi, pp.inv_rc, pp.tau, n2i, v, y);
+    // window of this workgroup's lags of the level (sorted: min / max of the tap bases)
+    int bmin = act ? base : 0x7fffffff, bmax = act ? base : -1;
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o1 = __shfl_xor(bmin, off, 64), o2 = __shfl_xor(bmax, off, 64);
+      bmin = o1 < bmin ? o1 : bmin;
+      bmax = o2 > bmax ? o2 : bmax;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_bmin[threadIdx.x >> 6] = bmin;
+      s_bmax[threadIdx.x >> 6] = bmax;
+    }
+    __syncthreads();
+    int wb = s_bmin[0], we = s_bmax[0];
+    for (int q = 1; q < 4; ++q) {
+      wb = s_bmin[q] < wb ? s_bmin[q] : wb;
+      we = s_bmax[q] > we ? s_bmax[q] : we;
+    }
+    const int wsize = we >= wb ? we - wb + W : 0;
+    const bool use_win = wsize > 0 && wsize <= kWinCap;
+    double wt[W];
+    if (act) es_weights<W>(ec->poly, y, wt);
+    const double zr = 2.0 * SK_PI * hp.om[level] * r;  // >= z0
+    const double izr = 1.0 / zr;
+    double sck = sqrt(izr);  // (2 pi om r)^-(k+1/2), k = 0
+    double a1r = 0, a1i = 0, a2r = 0, a2i = 0;  // sum_k i^k a_k sck H_k for both rules
+    for (int k = 0; k < hk_terms(W); ++k) {
+      const double2* g1 = db.hk_fft + ((int64_t)k * 2) * n2i;
+      const double2* g2 = g1 + n2i;
+      if (use_win) {
+        __syncthreads();  // previous term's taps consumed
+        for (int j = threadIdx.x; j < wsize; j += blockDim.x) {
+          s_hwin[j] = g1[wb + j];
+          s_hwin[kWinCap + j] = g2[wb + j];
+        }
+        __syncthreads();
+      }
+      if (act) {
+        double2 H1, H2;
+        if (use_win) tap_sums<W, true>(s_hwin + (base - wb), s_hwin + kWinCap + (base - wb), wt, H1, H2);
+        else tap_sums<W, true>(g1 + base, g2 + base, wt, H1, H2);
+        const double f = hp.a[k] * sck;
+        // multiply by i^k
+        double t1r, t1i, t2r, t2i;
+        switch (k & 3) {
+          case 0: t1r = H1.x; t1i = H1.y; t2r = H2.x; t2i = H2.y; break;
+          case 1: t1r = -H1.y; t1i = H1.x; t2r = -H2.y; t2i = H2.x; break;
+          case 2: t1r = -H1.x; t1i = -H1.y; t2r = -H2.x; t2i = -H2.y; break;
+          default: t1r = H1.y; t1i = -H1.x; t2r = H2.y; t2i = -H2.x; break;
+        }
+        a1r = fma(f, t1r, a1r); a1i = fma(f, t1i, a1i);
+        a2r = fma(f, t2r, a2r); a2i = fma(f, t2i, a2i);
+        sck *= izr;
+      }
+    }
+    if (act) {
+      double2 F1, F2;
+      interp_finish(dc, ec->cheb, r, pp.Cx, v, pp.theta_scale, make_double2(a1r, a1i), make_double2(a2r, a2i), F1, F2);
+      // Re{ e^{-i chi} F } sqrt(2/pi),  chi = (2 nu + 1) pi / 4
+      double sn, cs;
+      sincospi(0.25 * (2 * hp.nu + 1), &sn, &cs);
+      const double c0 = 0.79788456080286535588;  // sqrt(2/pi)
+      far1 = c0 * (cs * F1.x + sn * F1.y);
+      far2 = c0 * (cs * F2.x + sn * F2.y);
+    }
+  }
   if (act) {
     double I12[2] = {0.0, 0.0};
     // ---- near part: Chebyshev interpolant of the level's lag interval (or the sums taken at the lags themselves)
@@ -1434,43 +1507,8 @@ __global__ void __launch_bounds__(256) k_hk_interp(DevConst dc, const EsConst* e
         I12[rule] = fma(xx, b1, s_cheb[rule][0] - b2);
       }
     }
-    // ---- far part (levels below L only)
-    if (level < hp.L) {
-      double v, y;
-      const int base = tap_base<W>(r, pp.r_hi, pp.inv_rc, pp.tau, n2i, v, y);
-      double wt[W];
-      es_weights<W>(ec->poly, y, wt);
-      const double zr = 2.0 * SK_PI * hp.om[level] * r;  // >= z0
-      const double izr = 1.0 / zr;
-      double sck = sqrt(izr);  // (2 pi om r)^-(k+1/2), k = 0
-      double a1r = 0, a1i = 0, a2r = 0, a2i = 0;  // sum_k i^k a_k sck H_k for both rules
-      for (int k = 0; k < hk_terms(W); ++k) {
-        const double2* g1 = db.hk_fft + ((int64_t)k * 2) * n2i + base;
-        const double2* g2 = g1 + n2i;
-        double2 H1, H2;
-        tap_sums<W, true>(g1, g2, wt, H1, H2);
-        const double f = hp.a[k] * sck;
-        // multiply by i^k
-        double t1r, t1i, t2r, t2i;
-        switch (k & 3) {
-          case 0: t1r = H1.x; t1i = H1.y; t2r = H2.x; t2i = H2.y; break;
-          case 1: t1r = -H1.y; t1i = H1.x; t2r = -H2.y; t2i = H2.x; break;
-          case 2: t1r = -H1.x; t1i = -H1.y; t2r = -H2.x; t2i = -H2.y; break;
-          default: t1r = H1.y; t1i = -H1.x; t2r = H2.y; t2i = -H2.x; break;
-        }
-        a1r = fma(f, t1r, a1r); a1i = fma(f, t1i, a1i);
-        a2r = fma(f, t2r, a2r); a2i = fma(f, t2i, a2i);
-        sck *= izr;
-      }
-      double2 F1, F2;
-      interp_finish(dc, ec->cheb, r, pp.Cx, v, pp.theta_scale, make_double2(a1r, a1i), make_double2(a2r, a2i), F1, F2);
-      // Re{ e^{-i chi} F } sqrt(2/pi),  chi = (2 nu + 1) pi / 4
-      double sn, cs;
-      sincospi(0.25 * (2 * hp.nu + 1), &sn, &cs);
-      const double c0 = 0.79788456080286535588;  // sqrt(2/pi)
-      I12[0] += c0 * (cs * F1.x + sn * F1.y);
-      I12[1] += c0 * (cs * F2.x + sn * F2.y);
-    }
+    I12[0] += far1;
+    I12[1] += far2;
     if (raw != SK_RAW_NONE) {  // logw passes (src/quadrature.jl:208-219)
       double* out = db.lw_raw + (raw == SK_RAW_A ? 0 : 2 * n);
       out[i] = I12[0];
