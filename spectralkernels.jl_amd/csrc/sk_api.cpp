@@ -402,6 +402,8 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       hp.nu = nu;
       std::memcpy(hp.a, nu == nu_main ? cfg->hk_a : cfg->hk_a2, sizeof(hp.a));
       const double r_hi = hs->pp.r_hi, pb = hs->pp.pb;
+      hp.pa = hs->pp.pa;
+      hp.pb = pb;
       int L = 0;
       while (L < kHkMaxLevels - 1 && kHkZ0 * std::pow(kHkBeta, L + 1) / (2.0 * M_PI * r_hi) < pb) ++L;
       // level planning with the lag counts k_advance published: a level (and everything inside it) with at most

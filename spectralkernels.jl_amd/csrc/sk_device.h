@@ -34,6 +34,7 @@ struct HankelPlan {
   // [inner_lo, inner_lo + inner_cnt) instead of at Chebyshev nodes
   int direct_inner;
   long long inner_lo, inner_cnt;
+  double pa, pb;               // the (sub)panel, for bounding the near prefix by whole sub-panels
 };
 
 // Per-config constants, passed to kernels by value.

@@ -1295,6 +1295,9 @@ __global__ void __launch_bounds__(256) k_bessel(DevConst dc, DevBuffers db, int 
 // sources w < om_l (z < 8 z0 on the level's lag interval: a smooth function of r of bounded bandwidth)
 // are summed directly at 160 Chebyshev nodes of the interval and interpolated (Clenshaw) at the lags.
 
+// direct innermost level: node slots per lag (each slot = kHkSplit workgroups)
+__host__ __device__ inline int hk_direct_reps(long long cnt) { return cnt > 0 ? (int)(kHkNodes / cnt) : 1; }
+
 // level of lag r: number of edges edge[1..L] that are >= r
 __device__ __forceinline__ int hk_level(const HankelPlan& hp, double r) {
   int l = 0;
@@ -1344,21 +1347,35 @@ __global__ void __launch_bounds__(256) k_hk_near(DevConst dc, DevBuffers db, Han
   const double hi_r = hp.edge[level], lo_r = hp.edge[level + 1];
   const double half = 0.5 * (hi_r - lo_r), mid = 0.5 * (hi_r + lo_r);
   double r = mid + half * cospi((node + 0.5) / (double)kHkNodes);
-  if (hp.direct_inner && level == hp.L) {  // few lags: the sums are taken at the lags themselves
-    if (node >= hp.inner_cnt) {
-      if (threadIdx.x == 0) db.hk_nodes[(((int64_t)level * 2 + rule) * kHkNodes + node) * kHkSplit + split] = 0.0;
+  const int64_t M = dc.M, cnt = rule ? 2 * M : M;
+  int64_t lim = cnt;      // sources [0, lim) are shared out over `nsp` workgroups, this one is number `sp`
+  int nsp = kHkSplit, sp = split;
+  const double om = hp.om[level];
+  double* out = &db.hk_nodes[(((int64_t)level * 2 + rule) * kHkNodes + node) * kHkSplit + split];
+  if (hp.direct_inner && level == hp.L) {
+    // few lags: the sums are taken at the lags themselves; the idle node slots become extra splits of each lag
+    // (lag q owns slots q, q + cnt, q + 2 cnt, ...; k_hk_cheb adds them up)
+    const int reps = hk_direct_reps(hp.inner_cnt);
+    if (node >= reps * hp.inner_cnt) {
+      if (threadIdx.x == 0) *out = 0.0;
       return;
     }
-    r = db.xs[hp.inner_lo + node];
+    r = db.xs[hp.inner_lo + node % hp.inner_cnt];
+    nsp = reps * kHkSplit;
+    sp = (int)(node / hp.inner_cnt) * kHkSplit + split;
+  } else if (om < hp.pb) {
+    // the near set is a prefix of the sorted sources: bound it by whole sub-panels, so that all kHkSplit
+    // workgroups of the node share it (instead of the first one doing everything)
+    const double f = (om - hp.pa) / (hp.pb - hp.pa);
+    const int64_t nsub = f <= 0.0 ? 1 : (int64_t)floor(f * (double)dc.k) + 1;
+    if (nsub < dc.k) lim = nsub * (rule ? 2 * dc.m : dc.m);
   }
-  const double om = hp.om[level];
-  const int64_t M = dc.M, cnt = rule ? 2 * M : M;
   const double2* __restrict__ src = db.src + (rule ? M : 0);
   const double tw = 2.0 * SK_PI * r;
   double acc = 0.0;
-  const int64_t per = (cnt + kHkSplit - 1) / kHkSplit;
-  const int64_t jend = (split + 1) * per < cnt ? (split + 1) * per : cnt;
-  for (int64_t j = split * per + threadIdx.x; j < jend; j += blockDim.x) {
+  const int64_t per = (lim + nsp - 1) / nsp;
+  const int64_t jend = (sp + 1) * per < lim ? (sp + 1) * per : lim;
+  for (int64_t j = sp * per + threadIdx.x; j < jend; j += blockDim.x) {
     const double2 cw = src[j];
     if (!(cw.y < om)) break;  // sources are sorted by w: the near set is a prefix
     const double x = tw * cw.y;
@@ -1368,18 +1385,22 @@ __global__ void __launch_bounds__(256) k_hk_near(DevConst dc, DevBuffers db, Han
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0)
-    db.hk_nodes[(((int64_t)level * 2 + rule) * kHkNodes + node) * kHkSplit + split] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  if (threadIdx.x == 0) *out = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
 // node values -> Chebyshev coefficients (first-kind nodes): one workgroup per (level, rule)
-__global__ void __launch_bounds__(kHkNodes) k_hk_cheb(DevBuffers db, int direct_level) {
+__global__ void __launch_bounds__(kHkNodes) k_hk_cheb(DevBuffers db, int direct_level, long long direct_cnt) {
   __shared__ double f[kHkNodes];
   const double* in = db.hk_nodes + ((int64_t)blockIdx.x * kHkNodes + threadIdx.x) * kHkSplit;
   double fs = 0.0;
   for (int q = 0; q < kHkSplit; ++q) fs += in[q];
   f[threadIdx.x] = fs;
   if ((int)(blockIdx.x >> 1) == direct_level) {  // values at the lags themselves: no transform
+    if ((long long)threadIdx.x < direct_cnt) {
+      const int reps = hk_direct_reps(direct_cnt);
+      for (int m = 1; m < reps; ++m)  // the lag's other slots, fixed order
+        for (int q = 0; q < kHkSplit; ++q) fs += in[(int64_t)m * direct_cnt * kHkSplit + q];
+    }
     db.hk_cheb[(int64_t)blockIdx.x * kHkNodes + threadIdx.x] = fs;
     return;
   }
@@ -1602,7 +1623,8 @@ void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& d
 }
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st) {
   hipLaunchKernelGGL(k_hk_near, dim3((unsigned)((hp.L + 1) * 2 * kHkNodes * kHkSplit)), dim3(256), 0, st, dc, db, hp);
-  hipLaunchKernelGGL(k_hk_cheb, dim3((unsigned)((hp.L + 1) * 2)), dim3(kHkNodes), 0, st, db, hp.direct_inner ? hp.L : -1);
+  hipLaunchKernelGGL(k_hk_cheb, dim3((unsigned)((hp.L + 1) * 2)), dim3(kHkNodes), 0, st, db, hp.direct_inner ? hp.L : -1,
+                     hp.inner_cnt);
 }
 void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HankelPlan& hp, int level, int slot,
                       long long n, int raw, hipStream_t st) {
