@@ -298,7 +298,8 @@ struct EvScope {
 static int run_fft(sk_config* cfg, hipStream_t st) {
   FFTCHK(rocfft_execution_info_set_stream(cfg->info, st));
   void* in[1] = {cfg->db.fft};
-  FFTCHK(rocfft_execute(cfg->plan, in, nullptr, cfg->info));
+  void* out[1] = {cfg->db.fft_out};
+  FFTCHK(rocfft_execute(cfg->plan, in, out, cfg->info));
   return SK_OK;
 }
 
@@ -768,7 +769,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     if (rc) { sk_config_destroy(cfg); return rc; }         \
   } while (0)
   DA(2, db.state); DA(kStackCap, db.stack); DA(kTraceCap, db.trace);
-  DA((size_t)3 * cfg->M, db.src); DA((size_t)2 * dc.n2, db.fft);
+  DA((size_t)3 * cfg->M, db.src); DA((size_t)2 * dc.n2, db.fft); DA((size_t)2 * dc.n2, db.fft_out);
   DA((size_t)3 * cfg->M, cfg->d_fvals);
   DA(2, db.flags); DA(2, db.red);
   (void)hipMemset(db.flags, 0, 2 * sizeof(int));
@@ -790,7 +791,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   // rocFFT plan: length n2, batch 2 (m-rule and 2m-rule), in place, e^{+i...}
   std::call_once(g_fft_once, [] { rocfft_setup(); });
   size_t len[1] = {(size_t)dc.n2};
-  rocfft_status fs = rocfft_plan_create(&cfg->plan, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+  rocfft_status fs = rocfft_plan_create(&cfg->plan, rocfft_placement_notinplace, rocfft_transform_type_complex_inverse,
                                         rocfft_precision_double, 1, len, 2, nullptr);
   if (fs != rocfft_status_success) {
     sk_config_destroy(cfg);
@@ -1111,7 +1112,7 @@ int sk_panel_sums(sk_config* cfg, const double* nodes, const double* coef, size_
     launch_seam_deconv(dc, cfg->db.fft, st);
     rc = run_fft(cfg, st);
     if (rc) return done(rc);
-    launch_seam_interp(dc, cfg->d_ec, cfg->db.fft, d_xs, (int64_t)n, Cx, r_hi, tau, theta_scale, d_re, d_im, st);
+    launch_seam_interp(dc, cfg->d_ec, cfg->db.fft_out, d_xs, (int64_t)n, Cx, r_hi, tau, theta_scale, d_re, d_im, st);
   }
   if (hipMemcpyAsync(out_re, d_re, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipMemcpyAsync(out_im, d_im, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -1010,8 +1010,8 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
   const bool use_win = (wsize >= W && wsize <= kWinCap);
   if (use_win) {
     for (int j = threadIdx.x; j < wsize; j += 256) {
-      s_win[j] = db.fft[wbase + j];
-      s_win[kWinCap + j] = db.fft[n2i + wbase + j];
+      s_win[j] = db.fft_out[wbase + j];
+      s_win[kWinCap + j] = db.fft_out[n2i + wbase + j];
     }
   }
   __syncthreads();
@@ -1030,7 +1030,7 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
       off = off < 0 ? 0 : (off > wsize - W ? wsize - W : off);  // only ever clamps on unsorted (speculative) input
       tap_sums<W, true>(s_win + off, s_win + kWinCap + off, wt, H1, H2);
     } else {
-      tap_sums<W, true>(db.fft + base, db.fft + n2i + base, wt, H1, H2);
+      tap_sums<W, true>(db.fft_out + base, db.fft_out + n2i + base, wt, H1, H2);
     }
     interp_finish(dc, ec->cheb, r, pp.Cx, v, pp.theta_scale, H1, H2, F1, F2);
     if constexpr (RAW != SK_RAW_NONE) {
