@@ -128,7 +128,10 @@ class AdaptiveKernelConfig:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            L.load().sk_config_destroy(self._h)
+            try:
+                L.load().sk_config_destroy(self._h)
+            except Exception:  # interpreter shutdown: module globals may already be gone
+                pass
             self._h = None
 
     def rules(self, which="legendre"):
