@@ -9,10 +9,11 @@ import spectralkernels_jl_amd as sk
 from oracle import sk_oracle as oracle
 
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+OFFSET = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0
 t0 = time.time()
 for seed in range(nseeds):
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + seed + OFFSET)
     dim = [1, 1, 2][seed % 3]
     phi, rho, nu = rng.uniform(0.5, 3.0), 10.0 ** rng.uniform(-1.0, 0.7), rng.uniform(0.4, 2.2)
     mode = ["plain", "deriv", "logw", "plain"][(seed // 3) % 4]
