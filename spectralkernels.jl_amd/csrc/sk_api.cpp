@@ -69,6 +69,9 @@ struct sk_config {
   DevBuffers db;
   std::vector<void*> owned;  // device allocations freed at destroy
   rocfft_plan plan = nullptr;
+  rocfft_plan plan_seam = nullptr;  // sk_panel_sums
+  rocfft_execution_info info_seam = nullptr;
+  void* fft_work_seam = nullptr;
   rocfft_plan plan_hk = nullptr;   // batch 2*hk_terms(w), Hankel path
   void* fft_work_hk = nullptr;
   rocfft_execution_info info_hk = nullptr;
@@ -788,14 +791,34 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     sk_config_destroy(cfg);
     return fail(SK_EHIP, "hipStreamCreate failed");
   }
-  // rocFFT plan: length n2, batch 2 (m-rule and 2m-rule), in place, e^{+i...}
+  // rocFFT plans, e^{+i...}
   std::call_once(g_fft_once, [] { rocfft_setup(); });
-  size_t len[1] = {(size_t)dc.n2};
+  // four length-n1 transforms (even / odd output samples of both rules, see k_spread) instead of two of length n2
+  size_t len[1] = {(size_t)dc.n1};
   rocfft_status fs = rocfft_plan_create(&cfg->plan, rocfft_placement_notinplace, rocfft_transform_type_complex_inverse,
-                                        rocfft_precision_double, 1, len, 2, nullptr);
+                                        rocfft_precision_double, 1, len, 4, nullptr);
   if (fs != rocfft_status_success) {
     sk_config_destroy(cfg);
     return fail(SK_EHIP, "rocfft_plan_create failed");
+  }
+  {
+    // the finufft1d3-level seam (sk_panel_sums) keeps one plain length-n2 transform, in place
+    size_t lens[1] = {(size_t)dc.n2};
+    if (rocfft_plan_create(&cfg->plan_seam, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+                           rocfft_precision_double, 1, lens, 1, nullptr) != rocfft_status_success) {
+      sk_config_destroy(cfg);
+      return fail(SK_EHIP, "rocfft_plan_create (seam) failed");
+    }
+    size_t wbs = 0;
+    rocfft_plan_get_work_buffer_size(cfg->plan_seam, &wbs);
+    rocfft_execution_info_create(&cfg->info_seam);
+    if (wbs) {
+      if (hipMalloc(&cfg->fft_work_seam, wbs) != hipSuccess) {
+        sk_config_destroy(cfg);
+        return fail(SK_EHIP, "hipMalloc(fft work) failed");
+      }
+      rocfft_execution_info_set_work_buffer(cfg->info_seam, cfg->fft_work_seam, wbs);
+    }
   }
   size_t wb = 0;
   rocfft_plan_get_work_buffer_size(cfg->plan, &wb);
@@ -858,6 +881,9 @@ void sk_config_destroy(sk_config* cfg) {
   if (!cfg) return;
   hipSetDevice(cfg->device);
   if (cfg->plan) rocfft_plan_destroy(cfg->plan);
+  if (cfg->plan_seam) rocfft_plan_destroy(cfg->plan_seam);
+  if (cfg->info_seam) rocfft_execution_info_destroy(cfg->info_seam);
+  if (cfg->fft_work_seam) hipFree(cfg->fft_work_seam);
   if (cfg->plan_hk) rocfft_plan_destroy(cfg->plan_hk);
   if (cfg->info_hk) rocfft_execution_info_destroy(cfg->info_hk);
   if (cfg->fft_work_hk) hipFree(cfg->fft_work_hk);
@@ -1110,9 +1136,13 @@ int sk_panel_sums(sk_config* cfg, const double* nodes, const double* coef, size_
       return done(fail(SK_EHIP, "memset failed"));
     launch_seam_spread(dc, d_nodes, d_coef, (int64_t)M, Cx, X, kappa, cfg->db.fft, st);
     launch_seam_deconv(dc, cfg->db.fft, st);
-    rc = run_fft(cfg, st);
-    if (rc) return done(rc);
-    launch_seam_interp(dc, cfg->d_ec, cfg->db.fft_out, d_xs, (int64_t)n, Cx, r_hi, tau, theta_scale, d_re, d_im, st);
+    {
+      if (rocfft_execution_info_set_stream(cfg->info_seam, st) != rocfft_status_success) return done(fail(SK_EHIP, "rocFFT stream"));
+      void* in[1] = {cfg->db.fft};
+      if (rocfft_execute(cfg->plan_seam, in, nullptr, cfg->info_seam) != rocfft_status_success)
+        return done(fail(SK_EHIP, "rocfft_execute (seam) failed"));
+    }
+    launch_seam_interp(dc, cfg->d_ec, cfg->db.fft, d_xs, (int64_t)n, Cx, r_hi, tau, theta_scale, d_re, d_im, st);
   }
   if (hipMemcpyAsync(out_re, d_re, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipMemcpyAsync(out_im, d_im, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -579,22 +579,10 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
   int nitems = 0;
 #endif
   stage_es_tables<W>(ec, s_poly, nullptr);  // made visible by the first barrier of the tile loop
-  // Work items: the variant's tiles (heaviest first), then the zero padding of the FFT input.  The separate
-  // kernel is launched with one workgroup per item; the fused one with a grid that is resident at once, so
-  // that the state prologue is paid once per workgroup slot (items are taken with stride gridDim.x).
-  const int npadblk = (int)((2 * (n2 - n1) + kSpreadThreads - 1) / kSpreadThreads);
-  for (int item = blockIdx.x; item < ntiles + npadblk; item += gridDim.x) {
-    if (item >= ntiles) {
-      // zero padding of the FFT input: indices [n1 - n1/2, n2 - n1/2) of both rules
-      const int64_t npad = n2 - n1;
-      const int64_t g = ((int64_t)item - ntiles) * kSpreadThreads + tid;
-      if (g < 2 * npad) {
-        const int rule = g >= npad ? 1 : 0;
-        const int64_t off = rule ? g - npad : g;
-        db.fft[(int64_t)rule * n2 + (n1 - n1 / 2) + off] = make_double2(0.0, 0.0);
-      }
-      continue;
-    }
+  // Work items: the variant's tiles (heaviest first).  The separate kernel is launched with one workgroup per
+  // item; the fused one with a grid that is resident at once, so that the state prologue is paid once per
+  // workgroup slot (items are taken with stride gridDim.x).
+  for (int item = blockIdx.x; item < ntiles; item += gridDim.x) {
 #ifdef SK_STAMPS
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     ++nitems;
@@ -721,7 +709,14 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
       const int64_t l = (int64_t)(L0 + cell) - n1 / 2;
       // (-1)^l centres the FFT output (index k + n2/2), so k_interp never wraps around
       const double dcv = ((l & 1) ? -1.0 : 1.0) * dc.deconv[l < 0 ? -l : l];
-      db.fft[(int64_t)rule * n2 + (l < 0 ? l + n2 : l)] = make_double2(ar * dcv, ai * dcv);
+      // The length-n2 transform of the zero-padded grid, X[m] = sum_l x_l e^{2 pi i l m / n2}, as two length-n1
+      // transforms (no padding to write or to read, and rocFFT is faster on 4 x n1 than on 2 x n2):
+      //   X[2q] = sum_l x_l e^{2 pi i l q / n1},   X[2q+1] = sum_l (x_l e^{i pi l / n1}) e^{2 pi i l q / n1}.
+      const double xr = ar * dcv, xi = ai * dcv;
+      const double2 tw = cis_turns_small((double)l / (double)n2);  // |l| <= n1/2: l/n2 in [-1/4, 1/4]
+      const int64_t li = l < 0 ? l + n1 : l;
+      db.fft[(int64_t)(2 * rule) * n1 + li] = make_double2(xr, xi);
+      db.fft[(int64_t)(2 * rule + 1) * n1 + li] = make_double2(xr * tw.x - xi * tw.y, xr * tw.y + xi * tw.x);
     }
   }
   // the deferred tail fit, off the critical path: by the last workgroup after its items.  FUSED: this
@@ -1008,10 +1003,14 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
     wsize = tap_base<W>(r_b, pp.r_hi, pp.inv_rc, pp.tau, n2i, vv, yy) - wbase + W;
   }
   const bool use_win = (wsize >= W && wsize <= kWinCap);
+  // output sample m of rule R is element m >> 1 of transform 2R + (m & 1) (see k_spread)
+  const int n1i = n2i >> 1;
   if (use_win) {
     for (int j = threadIdx.x; j < wsize; j += 256) {
-      s_win[j] = db.fft_out[wbase + j];
-      s_win[kWinCap + j] = db.fft_out[n2i + wbase + j];
+      const int m = wbase + j;
+      const double2* src = db.fft_out + (size_t)(m & 1) * n1i + (m >> 1);
+      s_win[j] = src[0];
+      s_win[kWinCap + j] = src[2 * (size_t)n1i];
     }
   }
   __syncthreads();
@@ -1030,7 +1029,17 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
       off = off < 0 ? 0 : (off > wsize - W ? wsize - W : off);  // only ever clamps on unsorted (speculative) input
       tap_sums<W, true>(s_win + off, s_win + kWinCap + off, wt, H1, H2);
     } else {
-      tap_sums<W, true>(db.fft_out + base, db.fft_out + n2i + base, wt, H1, H2);
+      double h1r = 0, h1i = 0, h2r = 0, h2i = 0;
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        const int m = base + q;
+        const double2* src = db.fft_out + (size_t)(m & 1) * n1i + (m >> 1);
+        const double2 a1 = src[0], a2 = src[2 * (size_t)n1i];
+        h1r = fma(a1.x, wt[q], h1r); h1i = fma(a1.y, wt[q], h1i);
+        h2r = fma(a2.x, wt[q], h2r); h2i = fma(a2.y, wt[q], h2i);
+      }
+      H1 = make_double2(h1r, h1i);
+      H2 = make_double2(h2r, h2i);
     }
     interp_finish(dc, ec->cheb, r, pp.Cx, v, pp.theta_scale, H1, H2, F1, F2);
     if constexpr (RAW != SK_RAW_NONE) {
@@ -1584,8 +1593,7 @@ void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long 
 void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st) {
   // both variants have their own work list; launch for the longer one (extra blocks zero-pad or idle)
   const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
-  const unsigned padblk = nblk(2 * (dc.n2 - dc.n1), kSpreadThreads);
-  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_spread<W, false>), dim3(tiles + padblk), dim3(kSpreadThreads), 0, st, dc, ec, db,
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_spread<W, false>), dim3(tiles + 1), dim3(kSpreadThreads), 0, st, dc, ec, db,
                                          slot, 0, 0ll, 0.0, 0.0));
 }
 // workgroups of the fused kernel that are resident at once (so that the state prologue is paid once per slot)
@@ -1605,10 +1613,9 @@ static unsigned genspread_resident() {
 void launch_genspread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int mode, int t, long long n, double k0,
                       double ks0, hipStream_t st) {
   const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
-  const unsigned padblk = nblk(2 * (dc.n2 - dc.n1), kSpreadThreads);
   SK_DISPATCH_W(dc.w, {
     const unsigned res = genspread_resident<W>();
-    const unsigned grid = tiles + padblk < res ? tiles + padblk : res;  // items are taken with stride gridDim.x
+    const unsigned grid = tiles + 1 < res ? tiles + 1 : res;  // items are taken with stride gridDim.x
     hipLaunchKernelGGL((k_spread<W, true>), dim3(grid), dim3(kSpreadThreads), 0, st, dc, ec, db, t, mode, n, k0, ks0);
   });
 }
