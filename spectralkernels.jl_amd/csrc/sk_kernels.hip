@@ -601,10 +601,18 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
     NodeRef nr_next;
     nr_next.no = nr_next.wt = 0.0;
     nr_next.sp = 0;
-    if (jlo + tid < jhi) {
-      P_next = pos[jlo + tid];
-      if constexpr (FUSED) nr_next = node_fetch(dc, variant, rule, jlo + tid);
-      else c_next = src[jlo + tid];
+    // FUSED, at most 128 touching sources (most tiles): two threads share a source -- waves 0-1 make its kernel
+    // weights, waves 2-3 its strength -- which halves the staging phase, the longest of an item
+    const bool coop = FUSED && (jhi - jlo) <= kSpreadThreads / 2;
+    const int sidx = coop ? (tid & (kSpreadThreads / 2 - 1)) : tid;  // source slot of this thread within a batch
+    const int role = coop ? (tid >> 7) : 2;                           // 0: weights, 1: strength, 2: both
+    if (jlo + sidx < jhi) {
+      P_next = pos[jlo + sidx];
+      if constexpr (FUSED) {
+        if (role != 0) nr_next = node_fetch(dc, variant, rule, jlo + sidx);
+      } else {
+        c_next = src[jlo + sidx];
+      }
     }
     // lane mapping: tiles at the sub-panel edges have few cells but many sources, so the 64 lanes of
     // a wave are split as (cell, sub): `spl` lanes share one cell and take strided sources
@@ -628,20 +636,20 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
 #endif
     double ar = 0.0, ai = 0.0;
     for (int jb = jlo; jb < jhi; jb += kSpreadThreads) {
-      const int j = jb + tid;
+      const int j = jb + sidx;
       const int nb = (jhi - jb) < kSpreadThreads ? (jhi - jb) : kSpreadThreads;
       if (j < jhi) {
         const double P = P_next;
         if constexpr (FUSED) {
-          const NodeRef nr = nr_next;
-          if (j + kSpreadThreads < jhi) {  // prefetch the next batch
-            P_next = pos[j + kSpreadThreads];
-            nr_next = node_fetch(dc, variant, rule, j + kSpreadThreads);
+          if (role != 0) {
+            const NodeRef nr = nr_next;
+            if (!coop && j + kSpreadThreads < jhi) nr_next = node_fetch(dc, variant, rule, j + kSpreadThreads);
+            const double cj = node_strength(dc, pp, nr);
+            const double u = (P - 0.5 * (double)dc.n1) * dc.delta;
+            const double2 ph = cis_turns_prod(pp.kappa, u);  // type-3 pre-phase
+            s_c[sidx] = make_double2(cj * ph.x, cj * ph.y);
           }
-          const double cj = node_strength(dc, pp, nr);
-          const double u = (P - 0.5 * (double)dc.n1) * dc.delta;
-          const double2 ph = cis_turns_prod(pp.kappa, u);  // type-3 pre-phase
-          s_c[tid] = make_double2(cj * ph.x, cj * ph.y);
+          if (!coop && j + kSpreadThreads < jhi) P_next = pos[j + kSpreadThreads];  // prefetch the next batch
         } else {
           s_c[tid] = c_next;
           if (j + kSpreadThreads < jhi) {  // prefetch the next batch
@@ -649,18 +657,20 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
             c_next = src[j + kSpreadThreads];
           }
         }
-        const double tcn = P - 0.5 * W;
-        const double l0d = ceil(tcn);
-        const double y = (l0d - tcn) - 0.5;
-        const double y2 = y * y;
-        s_l0[tid] = (int)l0d - L0;
-        double* wrow = &s_w[tid * (W + 1)];
+        if (role != 1) {
+          const double tcn = P - 0.5 * W;
+          const double l0d = ceil(tcn);
+          const double y = (l0d - tcn) - 0.5;
+          const double y2 = y * y;
+          s_l0[sidx] = (int)l0d - L0;
+          double* wrow = &s_w[sidx * (W + 1)];
 #pragma unroll
-        for (int qq = 0; qq < W / 2; ++qq) {
-          double E, O;
-          es_pair<W>(s_poly, qq, y2, E, O);
-          wrow[qq] = fma(y, O, E);
-          wrow[W - 1 - qq] = fma(-y, O, E);
+          for (int qq = 0; qq < W / 2; ++qq) {
+            double E, O;
+            es_pair<W>(s_poly, qq, y2, E, O);
+            wrow[qq] = fma(y, O, E);
+            wrow[W - 1 - qq] = fma(-y, O, E);
+          }
         }
       }
       __syncthreads();
