@@ -429,8 +429,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       hp.edge[L + 1] = 0.0;
       launch_hk_near(cfg->dc, db, hp, st);
       for (int l = 0; l < L; ++l) {
-        launch_hk_gen(cfg->dc, db, hp, l, t & 1, st);
-        { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, st); }
+        { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hp.om[l], st); }
         {
           EvScope e(cfg, st, SK_K_FFT);
           FFTCHK(rocfft_execution_info_set_stream(cfg->info_hk, st));
@@ -848,16 +847,15 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
       }
       rocfft_execution_info_set_work_buffer(cfg->info_hk, cfg->fft_work_hk, wb2);
     }
-    void* p1 = nullptr; void* p2 = nullptr; void* p3 = nullptr; void* p4 = nullptr;
-    if (hipMalloc(&p1, sizeof(double2) * (size_t)kHkTerms * 3 * cfg->M) != hipSuccess ||
-        hipMalloc(&p2, sizeof(double2) * (size_t)kHkTerms * 2 * dc.n2) != hipSuccess ||
+    void* p2 = nullptr; void* p3 = nullptr; void* p4 = nullptr;
+    if (hipMalloc(&p2, sizeof(double2) * (size_t)kHkTerms * 2 * dc.n2) != hipSuccess ||
         hipMalloc(&p3, sizeof(double) * (size_t)(kHkMaxLevels + 1) * 2 * kHkNodes * kHkSplit) != hipSuccess ||
         hipMalloc(&p4, sizeof(double) * (size_t)(kHkMaxLevels + 1) * 2 * kHkNodes) != hipSuccess) {
       sk_config_destroy(cfg);
       return fail(SK_EHIP, "hipMalloc(Hankel buffers) failed");
     }
-    cfg->owned.push_back(p1); cfg->owned.push_back(p2); cfg->owned.push_back(p3); cfg->owned.push_back(p4);
-    db.hk_src = (double2*)p1; db.hk_fft = (double2*)p2; db.hk_nodes = (double*)p3; db.hk_cheb = (double*)p4;
+    cfg->owned.push_back(p2); cfg->owned.push_back(p3); cfg->owned.push_back(p4);
+    db.hk_fft = (double2*)p2; db.hk_nodes = (double*)p3; db.hk_cheb = (double*)p4;
     const int nu = args->derivative ? args->dim / 2 : args->dim / 2 - 1;
     cfg->hk_a[0] = 1.0;
     for (int kq = 1; kq < kHkTerms; ++kq)

@@ -160,7 +160,6 @@ struct DevBuffers {
   int* flags;               // input-check flags: [0] not strictly increasing, [1] negative or NaN lag
   int check_input;          // 1: the first k_gen of this call checks the lags (speculative sorted path)
   // Hankel path (dim >= 2)
-  double2* hk_src;          // kHkTerms x 3M scaled, pre-phased source strengths of the current level
   double2* hk_fft;          // kHkTerms x 2 x n2 complex grids of the current level
   double* hk_nodes;         // (kHkMaxLevels+1) x 2 x kHkNodes x kHkSplit partial near sums at the Chebyshev nodes
   double* hk_cheb;          // same shape: Chebyshev coefficients
@@ -181,8 +180,8 @@ void launch_genspread(const DevConst& dc, const EsConst* ec, const DevBuffers& d
 void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long n, int nu, int raw, hipStream_t st);
 // logw first panel: combine the raw sums of passes A and B with the boundary term (src/quadrature.jl:189,224-225)
 void launch_lw_finish(const DevConst& dc, const DevBuffers& db, int slot, long long n, double B0, hipStream_t st);
-void launch_hk_gen(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, int level, int slot, hipStream_t st);
-void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st);
+// far sources (w >= om) of one level: all series terms spread in one launch
+void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, double om, hipStream_t st);
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st);
 void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HankelPlan& hp, int level, int slot,
                       long long n, int raw, hipStream_t st);

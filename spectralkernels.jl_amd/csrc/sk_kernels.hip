@@ -740,16 +740,23 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
 #endif
 }
 
-// k_spread_multi: the same tile algorithm for the kHkTerms coefficient sets of the Hankel path in one
-// launch: the W kernel weights of a staged source are shared by all terms, only the strengths change.
-// Term k reads db.hk_src + k*3M and writes db.hk_fft + k*2*n2.
+// k_spread_multi: the tile algorithm of k_spread for the hk_terms(W) coefficient sets of the Hankel path in one
+// launch.  The W kernel weights of a staged source are shared by all terms; the strengths of every term are staged
+// together (batches of 128 sources), and the four waves of the workgroup each own a quarter of the TERMS for all
+// cells of the tile -- complete sums per wave, so no cross-wave reduction and two barriers per batch.
+// The strengths of term k, c_j (w_j/om)^-(k+1/2) times the type-3 pre-phase for the far sources w_j >= om of the
+// level (zero for the others), are generated while staging from (c_j, w_j) of k_gen -- no per-term strength arrays
+// in HBM.  Term k writes db.hk_fft + k*2*n2.
 template <int W>
-__global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, const EsConst* ec, DevBuffers db, int slot) {
+__global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, const EsConst* ec, DevBuffers db, int slot,
+                                                                 double om) {
   constexpr int NT = hk_terms(W);
-  __shared__ double s_w[kSpreadThreads * (W + 1)];
-  __shared__ double2 s_c[kSpreadThreads];
-  __shared__ int s_l0[kSpreadThreads];
-  __shared__ double2 s_red[kSpreadThreads];
+  constexpr int NB = 128;                       // sources per batch
+  constexpr int NPART = kSpreadThreads / 64;    // waves
+  constexpr int TPW = (NT + NPART - 1) / NPART; // terms per wave: k = part, part + NPART, ...
+  __shared__ double s_w[NB * (W + 1)];
+  __shared__ double2 s_ck[NT * NB];
+  __shared__ int s_l0[NB];
   __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
   const DevState& s = db.state[slot];
   if (s.done) return;
@@ -775,14 +782,13 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
   const int jlo = tl.z, jhi = tl.w;
   const int* __restrict__ cs = dc.cellstart[variant][rule];
   const double* __restrict__ pos = dc.pos[variant][rule];
-  const double2* __restrict__ src = db.hk_src + (rule ? dc.M : 0);
-  const int64_t sstride = 3 * dc.M;
+  const double2* __restrict__ src = db.src + (rule ? dc.M : 0);  // (c_j, w_j)
+  const double kappa = s.pp.kappa;
   int c2 = 64;
   while (c2 / 2 >= ncell && c2 > 1) c2 >>= 1;
   const int spl = 64 / c2;
   const int lane = tid & 63;
   const int part = tid >> 6;
-  constexpr int NPART = kSpreadThreads / 64;
   const int cell = lane / spl, sub = lane - cell * spl;
   int J0 = 0, J1 = 0;
   if (cell < ncell) {
@@ -792,14 +798,13 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
   }
   stage_es_tables<W>(ec, s_poly, nullptr);
   __syncthreads();
-  double ar[NT], ai[NT];
+  double ar[TPW], ai[TPW];
 #pragma unroll
-  for (int k = 0; k < NT; ++k) { ar[k] = 0.0; ai[k] = 0.0; }
-  for (int jb = jlo; jb < jhi; jb += kSpreadThreads) {
-    const int j = jb + tid;
-    const int nb = (jhi - jb) < kSpreadThreads ? (jhi - jb) : kSpreadThreads;
-    if (j < jhi) {
-      const double P = pos[j];
+  for (int q = 0; q < TPW; ++q) { ar[q] = 0.0; ai[q] = 0.0; }
+  for (int jb = jlo; jb < jhi; jb += NB) {
+    const int nb = (jhi - jb) < NB ? (jhi - jb) : NB;
+    if (tid < nb) {  // kernel weights of source jb + tid
+      const double P = pos[jb + tid];
       const double tcn = P - 0.5 * W;
       const double l0d = ceil(tcn);
       const double y = (l0d - tcn) - 0.5;
@@ -814,20 +819,42 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
         wrow[W - 1 - qq] = fma(-y, O, E);
       }
     }
-    const int j0 = (J0 > jb ? J0 : jb) - jb;
-    const int j1 = (J1 < jb + nb ? J1 : jb + nb) - jb;
+    if (tid >= NB && tid - NB < nb) {  // the other two waves: strengths of all terms of source jb + tid - NB
+      const int jj = tid - NB;
+      const double2 cw = src[jb + jj];
+      double scr = 0.0, sci = 0.0, q = 0.0;
+      if (cw.y >= om) {
+        const double u = (pos[jb + jj] - 0.5 * (double)dc.n1) * dc.delta;
+        const double2 ph = cis_turns_prod(kappa, u);
+        q = om / cw.y;                       // (w/om)^-1 in (0, 1]
+        const double sc = cw.x * sqrt(q);    // c (w/om)^-(k+1/2), k = 0
+        scr = sc * ph.x;
+        sci = sc * ph.y;
+      }
 #pragma unroll
-    for (int k = 0; k < NT; ++k) {
-      __syncthreads();  // weights staged (k == 0) / previous term's gather finished
-      if (j < jhi) s_c[tid] = src[(int64_t)k * sstride + j];
-      __syncthreads();
-      for (int jj = j0 + part * spl + sub; jj < j1; jj += NPART * spl) {
+      for (int k = 0; k < NT; ++k) {
+        s_ck[k * NB + jj] = make_double2(scr, sci);
+        scr *= q;
+        sci *= q;
+      }
+    }
+    __syncthreads();
+    {
+      const int j0 = (J0 > jb ? J0 : jb) - jb;
+      const int j1 = (J1 < jb + nb ? J1 : jb + nb) - jb;
+      for (int jj = j0 + sub; jj < j1; jj += spl) {
         const int rel = cell - s_l0[jj];
         if (rel >= 0 && rel < W) {
           const double wv = s_w[jj * (W + 1) + rel];
-          const double2 c = s_c[jj];
-          ar[k] = fma(c.x, wv, ar[k]);
-          ai[k] = fma(c.y, wv, ai[k]);
+#pragma unroll
+          for (int q = 0; q < TPW; ++q) {
+            const int k = part + q * NPART;
+            if (k < NT) {
+              const double2 c = s_ck[k * NB + jj];
+              ar[q] = fma(c.x, wv, ar[q]);
+              ai[q] = fma(c.y, wv, ai[q]);
+            }
+          }
         }
       }
     }
@@ -836,27 +863,17 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
   const int64_t l = (int64_t)(L0 + cell) - n1 / 2;
   const double dcv = (cell < ncell) ? ((l & 1) ? -1.0 : 1.0) * dc.deconv[l < 0 ? -l : l] : 0.0;
 #pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    double xr = ar[k], xi = ai[k];
-    for (int off = 1; off < spl; off <<= 1) {
+  for (int q = 0; q < TPW; ++q) {
+    const int k = part + q * NPART;
+    double xr = ar[q], xi = ai[q];
+    for (int off = 1; off < spl; off <<= 1) {  // sub-lanes of a cell (butterfly, fixed order)
       xr += __shfl_xor(xr, off, 64);
       xi += __shfl_xor(xi, off, 64);
     }
-    __syncthreads();
-    if (sub == 0) s_red[part * 64 + cell] = make_double2(xr, xi);
-    __syncthreads();
-    if (part == 0 && sub == 0 && cell < ncell) {
-#pragma unroll
-      for (int pidx = 1; pidx < NPART; ++pidx) {
-        xr += s_red[pidx * 64 + cell].x;
-        xi += s_red[pidx * 64 + cell].y;
-      }
+    if (k < NT && sub == 0 && cell < ncell)
       db.hk_fft[((int64_t)k * 2 + rule) * n2 + (l < 0 ? l + n2 : l)] = make_double2(xr * dcv, xi * dcv);
-    }
   }
 }
-
-// ------------------------------------------------------------------ interpolation core
 
 // Index of the first of the W interpolation taps of lag r in the centred FFT output (k_spread
 // multiplies by (-1)^l, so tap q sits at base + q with no wrap-around) and the kernel offset y.
@@ -1324,36 +1341,6 @@ __device__ __forceinline__ int hk_level(const HankelPlan& hp, double r) {
   return l;
 }
 
-// scaled, pre-phased strengths of the far sources of one level, all K terms: hk_src[k][rule-major j]
-__global__ void __launch_bounds__(256) k_hk_gen(DevConst dc, DevBuffers db, HankelPlan hp, int level, int slot) {
-  const DevState& s = db.state[slot];
-  if (s.done) return;
-  if (!state_sane(s, db, s.n)) return;
-  const PanelParams pp = s.pp;
-  const int64_t M = dc.M;
-  const int64_t jg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (jg >= 3 * M) return;
-  const int rule = jg < M ? 0 : 1;
-  const int64_t j = rule ? jg - M : jg;
-  const double2 cw = db.src[jg];  // (c_j, w_j) from k_gen
-  const double om = hp.om[level];
-  double2* out = db.hk_src + jg;
-  const int nterms = hk_terms(dc.w);
-  if (!(cw.y >= om)) {
-    for (int k = 0; k < nterms; ++k) out[(int64_t)k * 3 * M] = make_double2(0.0, 0.0);
-    return;
-  }
-  const double P = dc.pos[pp.jacobi][rule][j];
-  const double u = (P - 0.5 * (double)dc.n1) * dc.delta;
-  const double2 ph = cis_turns_prod(pp.kappa, u);
-  const double q = om / cw.y;       // (w/om)^-1 in (0, 1]
-  double sc = cw.x * sqrt(q);       // c (w/om)^-(k+1/2), k = 0
-  for (int k = 0; k < nterms; ++k) {
-    out[(int64_t)k * 3 * M] = make_double2(sc * ph.x, sc * ph.y);
-    sc *= q;
-  }
-}
-
 // near sums at the Chebyshev nodes: kHkSplit workgroups per (level, rule, node), each a contiguous
 // share of the sorted sources; the partial sums are added in fixed order by k_hk_cheb (deterministic)
 __global__ void __launch_bounds__(256) k_hk_near(DevConst dc, DevBuffers db, HankelPlan hp) {
@@ -1629,14 +1616,11 @@ void launch_genspread(const DevConst& dc, const EsConst* ec, const DevBuffers& d
     hipLaunchKernelGGL((k_spread<W, true>), dim3(grid), dim3(kSpreadThreads), 0, st, dc, ec, db, t, mode, n, k0, ks0);
   });
 }
-void launch_hk_gen(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, int level, int slot, hipStream_t st) {
-  hipLaunchKernelGGL(k_hk_gen, dim3(nblk(3 * dc.M, 256)), dim3(256), 0, st, dc, db, hp, level, slot);
-}
-void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st) {
+void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, double om, hipStream_t st) {
   // the fixed-geometry spread, all asymptotic terms in one launch
   const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
   SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_spread_multi<W>, dim3(tiles + 512), dim3(kSpreadThreads), 0, st, dc, ec, db,
-                                         slot));
+                                         slot, om));
 }
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st) {
   hipLaunchKernelGGL(k_hk_near, dim3((unsigned)((hp.L + 1) * 2 * kHkNodes * kHkSplit)), dim3(256), 0, st, dc, db, hp);
