@@ -111,6 +111,15 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
 int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double k0, int param_derivative,
                             double* d_vals, double* d_errs, void* stream);
 
+/* Several configs on ONE lag set -- the Jacobian pattern of src/derivatives.jl:61-112 (one kernel_values call per
+ * dS/dtheta_j integrand, one with derivative=true for the warping gradients, one with logw=true for d/dalpha, all
+ * at the same warp_lags).  The lags are uploaded, sorted and deduplicated once on the device; every config then
+ * marches on the sorted unique set with its own integrand and the results are scattered back per config.
+ * cfgs: ncfg configs on the same device; k0s / param_derivative: one entry per config (as in sk_kernel_values
+ * with has_k0 = 1); vals_out / errs_out: ncfg x n, row c = config c in input order. */
+int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, const double* k0s,
+                           const int* param_derivative, double* vals_out, double* errs_out);
+
 /* Callers' side of the path: lags from point pairs, generated on the device so that an n-point set never
  * materialises its n(n-1)/2 lags on the host.
  *   src/model.jl:64-65   warp_lags = [norm(warp_pts[j] - warp_pts[k]) for (j,k) in kernel_index_pairs]

@@ -57,6 +57,7 @@ def load():
     L.sk_compute_k0.argtypes = [vp, dp]
     L.sk_kernel_values.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp]
     L.sk_kernel_values_device.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_int, vp, vp, vp]
+    L.sk_kernel_values_multi.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp]
     L.sk_kernel_values_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp]
     L.sk_kernel_values_pairs_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_double, C.c_int, vp, vp, vp]
     L.sk_dense_cov_matrix.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]

@@ -197,6 +197,22 @@ def kernel_values_device(config, d_xs_ptr, n, k0, d_vals_ptr, d_errs_ptr, param_
                                             C.c_void_p(d_errs_ptr), C.c_void_p(stream_ptr)))
 
 
+def kernel_values_multi(configs, xs, k0s, param_derivative=False):
+    """Several configs at one lag set (the Jacobian pattern of src/derivatives.jl:61-112): one upload + device
+    sort / dedup, then every config's march.  k0s: scalar or one per config; param_derivative: bool or one per
+    config.  Returns (vals, errs) of shape (len(configs), len(xs))."""
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    nc, n = len(configs), xs.size
+    k0s = np.ascontiguousarray(np.broadcast_to(np.asarray(k0s, dtype=np.float64), (nc,)))
+    pds = np.ascontiguousarray(np.broadcast_to(np.asarray(param_derivative, dtype=bool), (nc,)).astype(np.int32))
+    handles = (C.c_void_p * nc)(*[c._h for c in configs])
+    vals, errs = np.zeros((nc, n)), np.zeros((nc, n))
+    _check(L.load().sk_kernel_values_multi(handles, nc, xs.ctypes.data_as(C.c_void_p), n, k0s.ctypes.data_as(C.c_void_p),
+                                           pds.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
+                                           errs.ctypes.data_as(C.c_void_p)))
+    return vals, errs
+
+
 def _points(pts):
     pts = np.ascontiguousarray(pts, dtype=np.float64)
     if pts.ndim == 1:

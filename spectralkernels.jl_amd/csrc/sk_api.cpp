@@ -974,6 +974,57 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
   return rc;
 }
 
+int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, const double* k0s,
+                           const int* param_derivative, double* vals_out, double* errs_out) {
+  if (!cfgs || ncfg == 0 || !cfgs[0]) return fail(SK_EINVAL, "null config");
+  for (size_t c = 0; c < ncfg; ++c)
+    if (!cfgs[c] || cfgs[c]->device != cfgs[0]->device) return fail(SK_EINVAL, "configs must live on one device");
+  if (n == 0) return SK_OK;
+  if (n > (size_t)0x7fffffff) return fail(SK_EINVAL, "at most 2^31-1 lags per call");
+  sk_config* c0 = cfgs[0];
+  HIPCHK(hipSetDevice(c0->device));
+  hipStream_t st = c0->own_stream;
+  // device buffers of this call: lags, sorted unique lags, inverse map, per-config unique results and gathered
+  // results, sort scratch
+  const size_t a8 = ((n * 8 + 255) / 256) * 256;
+  const size_t tb = sort_unique_temp_bytes((long long)n);
+  char* buf = nullptr;
+  HIPCHK(hipMalloc((void**)&buf, 7 * a8 + tb + 512));
+  auto done = [&](int rc) {
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    return rc;
+  };
+  double* d_xs = (double*)buf;
+  double* uxs = (double*)(buf + a8);
+  long long* inv = (long long*)(buf + 2 * a8);
+  double* ks = (double*)(buf + 3 * a8);
+  double* errs = (double*)(buf + 4 * a8);
+  double* gk = (double*)(buf + 5 * a8);
+  double* ge = (double*)(buf + 6 * a8);
+  long long* d_nu = (long long*)(buf + 7 * a8);
+  void* tmp = buf + 7 * a8 + 256;
+  if (hipMemcpyAsync(d_xs, xs, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+    return done(fail(SK_EHIP, "H2D copy failed"));
+  // src/adaptive.jl:99-120 once for all configs: unique + sort (the check for invalid lags is the first march's)
+  sort_unique(d_xs, (long long)n, uxs, inv, d_nu, tmp, tb, st);
+  if (hipMemcpyAsync(c0->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return done(fail(SK_EHIP, "sort failed"));
+  const long long nu = *c0->h_nuniq;
+  for (size_t c = 0; c < ncfg; ++c) {
+    int rc = sk_kernel_values_device(cfgs[c], uxs, (size_t)nu, k0s[c], param_derivative ? param_derivative[c] : 0, ks, errs,
+                                     st);
+    if (rc) return done(rc);
+    launch_gather(ks, errs, inv, (long long)n, gk, ge, st);
+    if (hipMemcpyAsync(vals_out + c * n, gk, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(errs_out + c * n, ge, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return done(fail(SK_EHIP, "D2H copy failed"));
+  }
+  return done(SK_OK);
+}
+
 // grow-only buffer of 3 n doubles: lags, values, errors of the pair entries
 static int ensure_lags(sk_config* cfg, size_t n) {
   const size_t need = 3 * n * sizeof(double);

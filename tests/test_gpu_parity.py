@@ -412,3 +412,21 @@ def test_config_lifecycle_and_interleaving(sk, oracle):
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < 64 * 2 ** 20  # destroyed configs gave their memory back
     assert np.abs(ka0 - oracle.matern_cov(rs, (1, 1, 1.5))).max() / ka0[0] <= 1e-7
+
+
+def test_multi_config_shared_lags_jacobian_pattern(sk, oracle):
+    # src/derivatives.jl:61-112: K, dK/dr (derivative=true) and dK/dalpha (logw=true) at the same lags, one call;
+    # must equal the separate kernel_values calls bit for bit (same sorted unique set, same marches)
+    rng = np.random.default_rng(11)
+    rs = np.concatenate([rng.uniform(0.0, 1.1, 900), [0.0], rng.uniform(0.0, 1.1, 100)])
+    rs[5] = rs[17]
+    parms, alpha = (2.14, 0.97, 0.89), 0.5
+    mk = lambda **kw: sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, 1), alpha=alpha, quadspec=(256, 16), **kw)
+    cfgs = [mk(), mk(derivative=True), mk(logw=True)]
+    k0 = sk.compute_k0(cfgs[0])
+    vals, errs = sk.kernel_values_multi(cfgs, rs, k0, param_derivative=[False, False, True])
+    for c, cfg in enumerate(cfgs):
+        v, e = sk.kernel_values(cfg, rs, k0=k0, param_derivative=(c == 2))
+        assert np.array_equal(vals[c], v) and np.array_equal(errs[c], e, equal_nan=True)
+    truth = oracle.sing_matern_cov(rs[rs > 0], -alpha, parms)
+    assert np.abs(vals[0][rs > 0] - truth).max() / k0 <= 10 * 1e-8
