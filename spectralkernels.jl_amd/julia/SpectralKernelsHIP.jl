@@ -8,7 +8,7 @@
 # exercised through its line-by-line ctypes mirror spectralkernels.jl_amd/api.py.)
 module SpectralKernelsHIP
 
-export AdaptiveKernelConfig, kernel_values, kernel_values_pairs, build_dense_cov_matrix, compute_k0, MaternSDF, ExponentialSDF, GaussianSDF
+export AdaptiveKernelConfig, kernel_values, kernel_values_multi, kernel_values_pairs, build_dense_cov_matrix, compute_k0, MaternSDF, ExponentialSDF, GaussianSDF
 
 const LIB = get(ENV, "SPECTRALKERNELS_HIP_LIB",
                 joinpath(@__DIR__, "..", "libspectralkernels_hip.so"))
@@ -115,6 +115,26 @@ function kernel_values(cfg::AdaptiveKernelConfig, xs::AbstractVector{Float64};
                  param_derivative ? 1 : 0, vals, errs))
   end
   (vals, errs)
+end
+
+# Several configs at one lag set -- kernel_sdf_derivatives / kernel_warping_gradients /
+# kernel_singularity_derivative (src/derivatives.jl:51-81) in one call: one upload, one device sort + dedup.
+# Returns a length(cfgs) x length(xs) matrix of values and one of error estimates.
+function kernel_values_multi(cfgs::AbstractVector{<:AdaptiveKernelConfig}, xs::AbstractVector{Float64};
+                             k0s, param_derivative=fill(false, length(cfgs)))
+  x    = Vector{Float64}(xs)
+  nc   = length(cfgs)
+  hs   = Ptr{Cvoid}[c.handle for c in cfgs]
+  ks   = Float64[k for k in (k0s isa Number ? fill(Float64(k0s), nc) : k0s)]
+  pd   = Cint[p ? 1 : 0 for p in param_derivative]
+  vals = Matrix{Float64}(undef, length(x), nc)                  # column c = config c (row-major nc x n on the C side)
+  errs = Matrix{Float64}(undef, length(x), nc)
+  GC.@preserve cfgs begin
+    _check(ccall((:sk_kernel_values_multi, LIB), Cint,
+                 (Ptr{Ptr{Cvoid}}, Csize_t, Ptr{Cdouble}, Csize_t, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}),
+                 hs, nc, x, length(x), ks, pd, vals, errs))
+  end
+  (permutedims(vals), permutedims(errs))
 end
 
 # Lags of point pairs formed on the device -- what gen_kernel_setup / gen_kernel do with
