@@ -430,3 +430,22 @@ def test_multi_config_shared_lags_jacobian_pattern(sk, oracle):
         assert np.array_equal(vals[c], v) and np.array_equal(errs[c], e, equal_nan=True)
     truth = oracle.sing_matern_cov(rs[rs > 0], -alpha, parms)
     assert np.abs(vals[0][rs > 0] - truth).max() / k0 <= 10 * 1e-8
+
+
+@pytest.mark.parametrize("dim", [4, 6])
+def test_higher_even_dims(sk, oracle, dim):
+    # isotropic kernels in dim 4 and 6 (nu = dim/2 - 1 = 1, 2): direct Bessel sums against the oracle and both paths
+    # against the closed-form Matern pair (scripts/matern_pair.jl:7-17 with d = dim)
+    parms = (1.3, 0.8, 1.2)
+    kw = dict(dim=dim, tol=1e-8, quadspec=(256, 16))
+    k0 = float(oracle.matern_cov(0.0, parms, d=dim))
+    rs = np.linspace(0.0, 2.0, 300)
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, dim), hankel_min_lags=-1, **kw)
+    assert abs(sk.compute_k0(cfg) - k0) / k0 <= 1e-10
+    ks, _ = sk.kernel_values(cfg, rs, k0=k0)
+    oks, _ = oracle.kernel_values(oracle.AdaptiveKernelConfig(oracle.SDF.matern(*parms, dim), **kw), rs, k0=k0)
+    assert np.abs(ks - oks).max() / k0 <= 1e-12
+    rs2 = np.linspace(0.0, 2.0, 3000)
+    cfg_h = sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, dim), hankel_min_lags=1, **kw)
+    kh, _ = sk.kernel_values(cfg_h, rs2, k0=k0)
+    assert np.abs(kh - oracle.matern_cov(rs2, parms, d=dim)).max() / k0 <= 10 * 1e-8
