@@ -1106,15 +1106,14 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
   if constexpr (RAW != SK_RAW_NONE) return;
   // wave reductions by shuffles (same-address LDS atomics from 64 lanes serialise and were 10 us slower),
   // then one LDS slot per wave; NaNs are carried by the flags (fmax drops them)
-  for (int off = 32; off > 0; off >>= 1) {
-    emax = fmax(emax, __shfl_xor(emax, off, 64));
-    const unsigned int o2 = __shfl_xor(unconv, off, 64);
-    unconv = o2 > unconv ? o2 : unconv;
-  }
+  for (int off = 32; off > 0; off >>= 1) emax = fmax(emax, __shfl_xor(emax, off, 64));
+  // the lag index ascends with the lane: the wave's highest unconverged lag sits in the highest flagged lane
+  const unsigned long long um = __ballot(unconv != 0u);
+  const unsigned int wave_unconv = um ? (unsigned int)(blk0 + (threadIdx.x & ~63u) + (63 - __builtin_clzll(um)) + 1) : 0u;
   const int a1 = __any(n1f), a2 = __any(n2f);
   if ((threadIdx.x & 63) == 0) {
     smax[threadIdx.x >> 6] = emax;
-    shi[threadIdx.x >> 6] = unconv;
+    shi[threadIdx.x >> 6] = wave_unconv;
     sflag[threadIdx.x >> 6][0] = a1;
     sflag[threadIdx.x >> 6][1] = a2;
   }
