@@ -960,6 +960,27 @@ __device__ __forceinline__ void interp_finish(const DevConst& dc, const double* 
   F1 = make_double2(H1.x * ph.x - H1.y * ph.y, H1.x * ph.y + H1.y * ph.x);
   F2 = make_double2(H2.x * ph.x - H2.y * ph.y, H2.x * ph.y + H2.y * ph.x);
 }
+// The same, but only the real (cos kernel) or only the imaginary (sin kernel) part of both sums.
+__device__ __forceinline__ void interp_finish_part(const DevConst& dc, const double* s_cheb, double r, double Cx, double v,
+                                                   double theta_scale, double2 H1, double2 H2, bool imag, double& f1,
+                                                   double& f2) {
+  const double th = (theta_scale * dc.inv_theta_max) * v;
+  double sarg = 2.0 * th * th - 1.0;
+  sarg = sarg > 1.0 ? 1.0 : sarg;
+  double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+  for (int kq = 15; kq >= 1; --kq) {
+    const double b0 = fma(2.0 * sarg, b1, s_cheb[kq] - b2);
+    b2 = b1;
+    b1 = b0;
+  }
+  const double invhat = fma(sarg, b1, s_cheb[0] - b2);
+  const double2 ph = cis_turns_prod(Cx, r);
+  // Re: H.x c - H.y s;  Im: H.x s + H.y c  -- one rotation coefficient pair, chosen once (wave-uniform)
+  const double p = (imag ? ph.y : ph.x) * invhat, q = (imag ? ph.x : -ph.y) * invhat;
+  f1 = fma(H1.y, q, H1.x * p);
+  f2 = fma(H2.y, q, H2.x * p);
+}
 
 // One evaluation of the current (sub)panel at the active lags, 256 lags per workgroup.  Per lag: read r and
 // the confirmed running sums, write the optimistic sums (other acc buffer) and, for lags that may retire with
@@ -1045,7 +1066,7 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
   int n1f = 0, n2f = 0;
   unsigned int unconv = 0u;
   if (act) {
-    double2 F1, F2;
+    double f1, f2;
     double v, y;
     const int base = tap_base<W>(r, pp.r_hi, pp.inv_rc, pp.tau, n2i, v, y);
     double wt[W];
@@ -1068,16 +1089,18 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
       H1 = make_double2(h1r, h1i);
       H2 = make_double2(h2r, h2i);
     }
-    interp_finish(dc, ec->cheb, r, pp.Cx, v, pp.theta_scale, H1, H2, F1, F2);
+    // only the part the kernel needs: real for :cos, imaginary for :sin (src/quadrature.jl:128-133)
+    const bool imag = (RAW == SK_RAW_B) || (RAW == SK_RAW_NONE && dc.derivative);
+    interp_finish_part(dc, ec->cheb, r, pp.Cx, v, pp.theta_scale, H1, H2, imag, f1, f2);
     if constexpr (RAW != SK_RAW_NONE) {
       // logw first panel (src/quadrature.jl:192-207): pass A keeps the cos sums, pass B the sin sums
       double* out = db.lw_raw + (RAW == SK_RAW_A ? 0 : 2 * n);
-      out[i] = (RAW == SK_RAW_A) ? F1.x : F1.y;
-      out[n + i] = (RAW == SK_RAW_A) ? F2.x : F2.y;
+      out[i] = f1;
+      out[n + i] = f2;
     } else {
       const double scale = dc.c;  // src/quadrature.jl:250-255 (dim == 1)
-      const double I1 = (dc.derivative ? F1.y : F1.x) * scale;
-      const double I2 = (dc.derivative ? F2.y : F2.x) * scale;
+      const double I1 = f1 * scale;
+      const double I2 = f2 * scale;
       const double e = fabs(I2 - I1);
       emax = e;
       n1f = isnan(I1);
