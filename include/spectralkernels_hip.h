@@ -159,7 +159,9 @@ int sk_last_stats(const sk_config* cfg, sk_stats* out);
 
 /* Per-kernel device timing of the hot path, measured with HIP events on the stream the kernels
  * are launched on.  Off by default (events add host overhead); when enabled every launch of the
- * next sk_kernel_values* calls is bracketed by two events.  Kernel ids: */
+ * next sk_kernel_values* calls is bracketed by two events.  Kernel ids (SK_K_GEN has no launches on the
+ * device-resident dim-1 path, where node generation is fused into the spread launch; SK_K_ADVANCE is the
+ * once-per-round status kernel; a config is not thread-safe: one call at a time per sk_config): */
 enum { SK_K_GEN = 0, SK_K_SPREAD = 1, SK_K_FFT = 2, SK_K_INTERP = 3, SK_K_ADVANCE = 4, SK_K_COUNT = 5 };
 typedef struct {
   double total_ms[SK_K_COUNT]; /* summed over the launches of the last call */
