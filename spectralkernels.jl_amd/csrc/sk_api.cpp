@@ -960,10 +960,6 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
   int rc = SK_OK;
   if (hipMemcpyAsync(d, xs, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
     rc = fail(SK_EHIP, "H2D copy failed");
-  if (getenv("SK_DBG_SYNC_H2D")) {
-    hipError_t e = hipStreamSynchronize(st);
-    fprintf(stderr, "[sk] H2D sync -> %s\n", hipGetErrorString(e));
-  }
   if (!rc) rc = sk_kernel_values_device(cfg, d, n, k0, param_derivative, d + n, d + 2 * n, st);
   if (!rc) {
     if (hipMemcpyAsync(vals_out, d + n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
