@@ -3,12 +3,13 @@
 # command; summaries land in gpurun_out/prof_round/ and are copied into profiles/ by hand.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_round
+WL=${1:-C2}
+OUT=$R/gpurun_out/prof_round${1:+_$1}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench $?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/stats.log 2>&1; echo "stats $?"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1; echo "pmc_fetch $?"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1; echo "pmc_write $?"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1; echo "pmc_sq $?"
+python3 $R/bench.py --workload $WL > $OUT/bench.json 2> $OUT/bench.err; echo "bench $?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline > $OUT/stats.log 2>&1; echo "stats $?"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --workload $WL --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1; echo "pmc_fetch $?"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --workload $WL --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1; echo "pmc_write $?"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --workload $WL --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1; echo "pmc_sq $?"
 python3 $R/tools/summarise_profiles.py $OUT > $OUT/summary.txt 2>&1; echo "summary $?"
