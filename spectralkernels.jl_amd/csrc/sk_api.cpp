@@ -84,6 +84,8 @@ struct sk_config {
   size_t ws_bytes = 0;
   double* d_io = nullptr;          // staging of sk_kernel_values (host arrays)
   size_t io_bytes = 0;
+  double* h_io = nullptr;          // pinned host staging of the same entry (lags, values, errors)
+  size_t hio_bytes = 0;
   double* d_lags = nullptr;        // values / errors staging of the pair entries (3 n doubles)
   size_t lags_bytes = 0;
   double* d_plags = nullptr;       // pairwise lags generated on the device
@@ -890,6 +892,7 @@ void sk_config_destroy(sk_config* cfg) {
   for (void* p : cfg->owned) hipFree(p);
   if (cfg->ws) hipFree(cfg->ws);
   if (cfg->d_io) hipFree(cfg->d_io);
+  if (cfg->h_io) hipHostFree(cfg->h_io);
   if (cfg->d_lags) hipFree(cfg->d_lags);
   if (cfg->d_plags) hipFree(cfg->d_plags);
   if (cfg->h_status) hipHostFree(cfg->h_status);
@@ -957,15 +960,45 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
   }
   double* d = cfg->d_io;
   hipStream_t st = cfg->own_stream;
+  // Large calls go through a pinned staging buffer filled / drained by all host threads: a pageable
+  // hipMemcpy of 24 MB costs ~3.5 ms on this stack (single-threaded staging inside the runtime), the same bytes
+  // take ~0.5 ms as parallel memcpy + DMA from pinned memory.
+  const bool pinned = n >= (size_t)1 << 15;
+  if (pinned && 3 * n * sizeof(double) > cfg->hio_bytes) {
+    if (cfg->h_io) HIPCHK(hipHostFree(cfg->h_io));
+    cfg->h_io = nullptr;
+    cfg->hio_bytes = 0;
+    HIPCHK(hipHostMalloc((void**)&cfg->h_io, 3 * n * sizeof(double) + 3 * n * sizeof(double) / 4, hipHostMallocDefault));
+    cfg->hio_bytes = 3 * n * sizeof(double) + 3 * n * sizeof(double) / 4;
+  }
+  auto par_copy = [](double* dst, const double* src, size_t cnt) {
+    const long long chunks = (long long)((cnt + 65535) / 65536);
+#pragma omp parallel for schedule(static) num_threads(8)
+    for (long long c = 0; c < chunks; ++c) {
+      const size_t lo = (size_t)c * 65536, len = cnt - lo < 65536 ? cnt - lo : 65536;
+      std::memcpy(dst + lo, src + lo, len * sizeof(double));
+    }
+  };
   int rc = SK_OK;
-  if (hipMemcpyAsync(d, xs, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+  const double* h_src = xs;
+  if (pinned) {
+    par_copy(cfg->h_io, xs, n);
+    h_src = cfg->h_io;
+  }
+  if (hipMemcpyAsync(d, h_src, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
     rc = fail(SK_EHIP, "H2D copy failed");
   if (!rc) rc = sk_kernel_values_device(cfg, d, n, k0, param_derivative, d + n, d + 2 * n, st);
   if (!rc) {
-    if (hipMemcpyAsync(vals_out, d + n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(errs_out, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+    double* hv = pinned ? cfg->h_io + n : vals_out;
+    double* he = pinned ? cfg->h_io + 2 * n : errs_out;
+    if (hipMemcpyAsync(hv, d + n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(he, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       rc = fail(SK_EHIP, "D2H copy failed");
+    if (!rc && pinned) {
+      par_copy(vals_out, hv, n);
+      par_copy(errs_out, he, n);
+    }
   }
   return rc;
 }
