@@ -941,6 +941,60 @@ int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double
   return kernel_values_device_impl(cfg, d_xs, n, k0, ks0, d_vals, d_errs, st);
 }
 
+// Host <-> device copies of large host arrays through a pinned staging buffer filled / drained by several host
+// threads: a pageable hipMemcpy of 24 MB costs ~3.5 ms on this stack (single-threaded staging inside the
+// runtime); the same bytes take ~1 ms as parallel memcpy + DMA from / to pinned memory.
+static const size_t kPinnedMin = (size_t)1 << 15;  // doubles; smaller arrays are copied directly
+static void par_copy(double* dst, const double* src, size_t cnt) {
+  const long long chunks = (long long)((cnt + 65535) / 65536);
+#pragma omp parallel for schedule(static) num_threads(8)
+  for (long long c = 0; c < chunks; ++c) {
+    const size_t lo = (size_t)c * 65536, len = cnt - lo < 65536 ? cnt - lo : 65536;
+    std::memcpy(dst + lo, src + lo, len * sizeof(double));
+  }
+}
+static int ensure_pinned(sk_config* cfg, size_t doubles) {
+  if (doubles * sizeof(double) <= cfg->hio_bytes) return SK_OK;
+  if (cfg->h_io) HIPCHK(hipHostFree(cfg->h_io));
+  cfg->h_io = nullptr;
+  cfg->hio_bytes = 0;
+  const size_t bytes = doubles * sizeof(double) + doubles * sizeof(double) / 4;
+  HIPCHK(hipHostMalloc((void**)&cfg->h_io, bytes, hipHostMallocDefault));
+  cfg->hio_bytes = bytes;
+  return SK_OK;
+}
+// device -> host, synchronous on `st`
+static int d2h_doubles(sk_config* cfg, double* dst, const double* d_src, size_t cnt, hipStream_t st) {
+  if (cnt < kPinnedMin) {
+    if (hipMemcpyAsync(dst, d_src, cnt * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return fail(SK_EHIP, "D2H copy failed");
+    return SK_OK;
+  }
+  int rc = ensure_pinned(cfg, cnt);
+  if (rc) return rc;
+  if (hipMemcpyAsync(cfg->h_io, d_src, cnt * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return fail(SK_EHIP, "D2H copy failed");
+  par_copy(dst, cfg->h_io, cnt);
+  return SK_OK;
+}
+// host -> device; returns after the copy has been enqueued AND the staging buffer may be reused
+static int h2d_doubles(sk_config* cfg, double* d_dst, const double* src, size_t cnt, hipStream_t st) {
+  if (cnt < kPinnedMin) {
+    if (hipMemcpyAsync(d_dst, src, cnt * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+      return fail(SK_EHIP, "H2D copy failed");
+    return SK_OK;
+  }
+  int rc = ensure_pinned(cfg, cnt);
+  if (rc) return rc;
+  par_copy(cfg->h_io, src, cnt);
+  if (hipMemcpyAsync(d_dst, cfg->h_io, cnt * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return fail(SK_EHIP, "H2D copy failed");
+  return SK_OK;
+}
+
 int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int has_k0, int param_derivative,
                      double* vals_out, double* errs_out) {
   if (!cfg) return fail(SK_EINVAL, "null config");
@@ -960,46 +1014,10 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
   }
   double* d = cfg->d_io;
   hipStream_t st = cfg->own_stream;
-  // Large calls go through a pinned staging buffer filled / drained by all host threads: a pageable
-  // hipMemcpy of 24 MB costs ~3.5 ms on this stack (single-threaded staging inside the runtime), the same bytes
-  // take ~0.5 ms as parallel memcpy + DMA from pinned memory.
-  const bool pinned = n >= (size_t)1 << 15;
-  if (pinned && 3 * n * sizeof(double) > cfg->hio_bytes) {
-    if (cfg->h_io) HIPCHK(hipHostFree(cfg->h_io));
-    cfg->h_io = nullptr;
-    cfg->hio_bytes = 0;
-    HIPCHK(hipHostMalloc((void**)&cfg->h_io, 3 * n * sizeof(double) + 3 * n * sizeof(double) / 4, hipHostMallocDefault));
-    cfg->hio_bytes = 3 * n * sizeof(double) + 3 * n * sizeof(double) / 4;
-  }
-  auto par_copy = [](double* dst, const double* src, size_t cnt) {
-    const long long chunks = (long long)((cnt + 65535) / 65536);
-#pragma omp parallel for schedule(static) num_threads(8)
-    for (long long c = 0; c < chunks; ++c) {
-      const size_t lo = (size_t)c * 65536, len = cnt - lo < 65536 ? cnt - lo : 65536;
-      std::memcpy(dst + lo, src + lo, len * sizeof(double));
-    }
-  };
-  int rc = SK_OK;
-  const double* h_src = xs;
-  if (pinned) {
-    par_copy(cfg->h_io, xs, n);
-    h_src = cfg->h_io;
-  }
-  if (hipMemcpyAsync(d, h_src, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
-    rc = fail(SK_EHIP, "H2D copy failed");
+  int rc = h2d_doubles(cfg, d, xs, n, st);
   if (!rc) rc = sk_kernel_values_device(cfg, d, n, k0, param_derivative, d + n, d + 2 * n, st);
-  if (!rc) {
-    double* hv = pinned ? cfg->h_io + n : vals_out;
-    double* he = pinned ? cfg->h_io + 2 * n : errs_out;
-    if (hipMemcpyAsync(hv, d + n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(he, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-      rc = fail(SK_EHIP, "D2H copy failed");
-    if (!rc && pinned) {
-      par_copy(vals_out, hv, n);
-      par_copy(errs_out, he, n);
-    }
-  }
+  if (!rc) rc = d2h_doubles(cfg, vals_out, d + n, n, st);
+  if (!rc) rc = d2h_doubles(cfg, errs_out, d + 2 * n, n, st);
   return rc;
 }
 
@@ -1033,8 +1051,10 @@ int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs
   double* ge = (double*)(buf + 6 * a8);
   long long* d_nu = (long long*)(buf + 7 * a8);
   void* tmp = buf + 7 * a8 + 256;
-  if (hipMemcpyAsync(d_xs, xs, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
-    return done(fail(SK_EHIP, "H2D copy failed"));
+  {
+    int rc = h2d_doubles(c0, d_xs, xs, n, st);
+    if (rc) return done(rc);
+  }
   // src/adaptive.jl:99-120 once for all configs: unique + sort (the check for invalid lags is the first march's)
   sort_unique(d_xs, (long long)n, uxs, inv, d_nu, tmp, tb, st);
   if (hipMemcpyAsync(c0->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -1046,10 +1066,9 @@ int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs
                                      st);
     if (rc) return done(rc);
     launch_gather(ks, errs, inv, (long long)n, gk, ge, st);
-    if (hipMemcpyAsync(vals_out + c * n, gk, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(errs_out + c * n, ge, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-      return done(fail(SK_EHIP, "D2H copy failed"));
+    rc = d2h_doubles(c0, vals_out + c * n, gk, n, st);
+    if (!rc) rc = d2h_doubles(c0, errs_out + c * n, ge, n, st);
+    if (rc) return done(rc);
   }
   return done(SK_OK);
 }
@@ -1117,11 +1136,8 @@ int sk_kernel_values_pairs(sk_config* cfg, const double* pts, size_t npts, int p
     rc = fail(SK_EHIP, "H2D copy failed");
   double* d = cfg->d_lags;
   if (!rc) rc = sk_kernel_values_pairs_device(cfg, d_pts, npts, pdim, d_pairs, npairs, k0, param_derivative, d + n, d + 2 * n, st);
-  if (!rc) {
-    if (hipMemcpyAsync(vals_out, d + n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(errs_out, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
-      rc = fail(SK_EHIP, "D2H copy failed");
-  }
+  if (!rc) rc = d2h_doubles(cfg, vals_out, d + n, n, st);
+  if (!rc) rc = d2h_doubles(cfg, errs_out, d + 2 * n, n, st);
   if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(SK_EHIP, "stream synchronisation failed");
   (void)hipFree(d_pts);
   if (d_pairs) (void)hipFree(d_pairs);
@@ -1162,9 +1178,7 @@ int sk_dense_cov_matrix(sk_config* cfg, const double* pts, size_t npts, int pdim
   if (hipMemcpyAsync(d_pts, pts, npts * pdim * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
     rc = fail(SK_EHIP, "H2D copy failed");
   if (!rc) rc = sk_dense_cov_matrix_device(cfg, d_pts, npts, pdim, d_out, st);
-  if (!rc && (hipMemcpyAsync(out, d_out, npts * npts * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-              hipStreamSynchronize(st) != hipSuccess))
-    rc = fail(SK_EHIP, "D2H copy failed");
+  if (!rc) rc = d2h_doubles(cfg, out, d_out, npts * npts, st);
   (void)hipFree(d_pts);
   (void)hipFree(d_out);
   return rc;
