@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- r-targets/sec through kernel_values on MI355X (BASELINE.json metric).
 
-One "step" = one kernel_values pass over one batch of synthetic lags that are already resident
-in HBM (sk_kernel_values_device): BASELINE config 2 by default -- Matern nu=3/2 SDF
-S(w) = (1+w^2)^-2, 10^6 log-spaced r in [1e-6, 1], tol = 1e-8, quadspec (4096, 16).
-Multi-GPU: one process per GPU, every rank marches its own 10^6-lag shard of the r-set
-(weak scaling, no data-path collective); the only exchange is the K(0) normaliser, whose
-quadrature is split over the ranks and summed with one all-reduce (RCCL) at set-up.
+One "step" = one kernel_values pass over one batch of synthetic lags: BASELINE config 2 by default -- Matern
+nu=3/2 SDF S(w) = (1+w^2)^-2, 10^6 log-spaced r in [1e-6, 1], tol = 1e-8, quadspec (4096, 16).
 
+  value         lags already resident in HBM when the timed region starts (sk_kernel_values_device)
+  host_to_host  the reference-shaped call (src/adaptive.jl:95-108: host Vector in, two host Vectors out) on the
+                same lags through sk_kernel_values: sorted, permuted with duplicates, and from pinned arrays --
+                SURVEY 8(d)'s "host entry -> results in host memory" span; cpu_baseline is quoted against it
+
+Multi-GPU: one process per GPU (torch.distributed over RCCL); every rank marches its own 10^6-lag shard of the
+r-set (weak scaling, no data-path collective); the only exchange is the K(0) normaliser, whose quadrature is split
+over the ranks and summed with one all-reduce at set-up.  --shard strided (default): rank r takes every N-th lag of
+the N*10^6 grid (same r-range, same panel schedule on every rank); --shard blocked: contiguous blocks (each rank
+its own r-range and schedule -- per-rank ms and panel counts in the JSON line show the imbalance).
+
+At N = 1 no torch / second HIP runtime is loaded into the process: device buffers come from the library's own ABI.
 Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement").
 """
 import argparse
+import ctypes.util
 import json
 import os
+import shutil
 import sys
 import time
 
@@ -20,13 +30,15 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+ROUND = "r02"
 
 WORKLOADS = {
     # name: (sdf kind, params, config kwargs, r-grid builder, k0, truth)
     "C2": dict(desc="Matern nu=3/2 S=(1+w^2)^-2, 1e6 log-spaced r in [1e-6,1], tol=1e-8, quadspec=(4096,16)",
                sdf=("matern", (1.0, 1.0, 1.5)), kw=dict(tol=1e-8), n=10 ** 6, lo=-6.0, hi=0.0),
     "C4": dict(desc="dim=2 isotropic S=0.7(1.3^2+w^2)^-2.8 (scripts/simple_2d.jl), 1e6 pairwise lags |x_i-y_j| of 1e3 x 1e3 "
-                    "splitmix64-seeded uniform points in [0,1]^2, tol=1e-8, quadspec=(4096,16); direct Bessel-sum kernel",
+                    "splitmix64-seeded uniform points in [0,1]^2, tol=1e-8, quadspec=(4096,16); fast Hankel transform "
+                    "(asymptotic-series NUFFTs + near-field Chebyshev interpolants)",
                sdf=("matern", (0.7, 1.3, 1.8, 2.0)), kw=dict(tol=1e-8, dim=2), n=10 ** 6, lo=None, hi=None),
     "C5": dict(desc="Matern (2.14,0.97,0.89), 1e5 uniform r in [0,5.1], tol=1e-12, quadspec=(256,16)",
                sdf=("matern", (2.14, 0.97, 0.89)), kw=dict(tol=1e-12, quadspec=(256, 16)), n=10 ** 5, lo=None, hi=5.1),
@@ -51,13 +63,17 @@ def splitmix64(seed, count):
     return out
 
 
-def shard_grid(w, rank, world):
-    """Rank `rank` of `world` gets every world-th lag of the world*n log-spaced global grid."""
+def c4_points(m=1000):
+    u = splitmix64(123, 4 * m).reshape(4, m)
+    return np.stack([u[0], u[1]], 1), np.stack([u[2], u[3]], 1)
+
+
+def shard_grid(w, rank, world, mode="strided"):
+    """This rank's lags of the world*n global set: every world-th lag (strided) or a contiguous block (blocked)."""
     n = w["n"]
     if w["hi"] is None:  # C4: pairwise distances between two seeded point sets, rows of X sharded over ranks
         m = int(round(np.sqrt(n)))
-        u = splitmix64(123, 4 * m).reshape(4, m)
-        X, Y = np.stack([u[0], u[1]], 1), np.stack([u[2], u[3]], 1)
+        X, Y = c4_points(m)
         rows = np.arange(rank, m, world) if world > 1 else np.arange(m)
         d = np.sqrt(((X[rows, None, :] - Y[None, :, :]) ** 2).sum(-1)).ravel()
         return np.ascontiguousarray(d)
@@ -65,7 +81,32 @@ def shard_grid(w, rank, world):
         g = np.linspace(0.0, w["hi"], n * world)
     else:
         g = 10.0 ** np.linspace(w["lo"], w["hi"], n * world)
+    if mode == "blocked":
+        return np.ascontiguousarray(g[rank * n:(rank + 1) * n])
     return np.ascontiguousarray(g[rank::world])
+
+
+def reference_probe():
+    """Is the true reference path (Julia + FINUFFT, README.md:38-48) runnable on this box?  SURVEY 8(d)."""
+    found = {"julia": shutil.which("julia"), "libfinufft": ctypes.util.find_library("finufft")}
+    try:
+        import finufft  # noqa: F401
+        found["python_finufft"] = True
+    except Exception:
+        found["python_finufft"] = False
+    ok = bool(found["julia"]) or bool(found["libfinufft"]) or found["python_finufft"]
+    return ("available" if ok else "unavailable"), found
+
+
+def timed(fn, steps, warmup, fence):
+    for _ in range(warmup):
+        fn()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    fence()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -74,22 +115,26 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--shard", default="strided", choices=("strided", "blocked"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="lags in the CPU-baseline sample (0 = auto)")
     args = ap.parse_args()
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dist = None
+    dist = torch = None
     if world > 1:
+        # torch (and with it RCCL) only in the multi-process case; it is imported before the HIP library so that
+        # one HIP runtime serves both ("One HIP runtime per process")
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import spectralkernels_jl_amd as sk
@@ -101,55 +146,49 @@ def main():
         from scipy import special
         q = (1 - 0.4) / 2
         prm = (1.0 / (10.0 ** (1 - 0.4 - 2 * 1.0) * special.beta(q, 1.0 - q)), 10.0, 0.5)
-    cfg = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), **w["kw"])
+    cfg = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), device=local_rank, **w["kw"])
 
     # shared K(0) normaliser: quadrature split over ranks + one all-reduce (RCCL over xGMI)
     if args.workload == "C3":
         k0 = 1.0  # normalised by the closed form; the reference's own QuadGK call fails on this SDF (demo TODO)
     else:
-        k0 = skdist.shared_k0(cfg, dist, torch.device("cuda", local_rank))
+        k0 = skdist.shared_k0(cfg, dist, torch.device("cuda", local_rank) if torch else None)
 
-    rs = shard_grid(w, rank, world)
+    rs = shard_grid(w, rank, world, args.shard)
     n = rs.size
-    d_rs = torch.from_numpy(rs).cuda()
-    d_ks = torch.empty_like(d_rs)
-    d_errs = torch.empty_like(d_rs)
-    stream = torch.cuda.current_stream().cuda_stream
+    d_rs = sk.DeviceArray.from_host(rs, device=local_rank)
+    d_ks, d_errs = sk.DeviceArray(n, local_rank), sk.DeviceArray(n, local_rank)
 
     def step():
-        sk.kernel_values_device(cfg, d_rs.data_ptr(), n, k0, d_ks.data_ptr(), d_errs.data_ptr(), stream_ptr=stream)
+        sk.kernel_values_device(cfg, d_rs.ptr, n, k0, d_ks.ptr, d_errs.ptr)
 
     def fence():
-        torch.cuda.synchronize()
+        sk.synchronize(local_rank)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            sk.synchronize(local_rank)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt_local = timed(step, args.steps, args.warmup, fence)
+    dt = dt_local
+    per_rank = None
+    st = cfg.last_stats()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = 1e3 * dt / args.steps
-    n_all = n
-    if dist is not None and args.workload == "C4":  # sharded fixed problem: count every rank's lags
-        tn = torch.tensor([n], dtype=torch.int64, device="cuda")
-        dist.all_reduce(tn)
-        n_all = int(tn.item())
-        value = n_all / (dt / args.steps)
+        t = torch.tensor([dt_local, float(st["n_panels"]), float(st["n_outer"]), float(n), float(st["sum_active"])],
+                         dtype=torch.float64, device="cuda")
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rows = [x.cpu().numpy() for x in allt]
+        dt = max(r[0] for r in rows)
+        per_rank = [{"rank": i, "ms_per_step": 1e3 * r[0] / args.steps, "n_panels": int(r[1]), "n_outer": int(r[2]),
+                     "lags": int(r[3]), "abar": r[4] / max(1.0, r[3])} for i, r in enumerate(rows)]
+        n_all = int(sum(r[3] for r in rows))
     else:
-        value = world * n / (dt / args.steps)
+        n_all = n
+    ms_per_step = 1e3 * dt / args.steps
+    value = n_all / (dt / args.steps)
 
     # ---- accuracy of this rank's shard against the closed form
-    ks = d_ks.cpu().numpy()
-    st = cfg.last_stats()
+    ks = d_ks.to_host()
     if args.workload == "C2":
         truth = k0 * (1 + 2 * np.pi * rs) * np.exp(-2 * np.pi * rs)
         max_rel_err = float(np.abs(ks - truth).max() / abs(k0))
@@ -159,6 +198,46 @@ def main():
         max_rel_err = float(np.abs(ks - o.matern_cov(rs, prm[:3], d=d)).max() / abs(k0))
     else:
         max_rel_err = None
+
+    # ---- the reference-shaped call: host arrays in, host arrays out (rank 0, N = 1)
+    host = None
+    if rank == 0 and world == 1 and not args.no_host_leg:
+        hsteps, hwarm = max(5, min(args.steps, 30)), 3
+        nofence = lambda: None  # sk_kernel_values returns with the results in the caller's arrays
+        legs = {}
+        io_bytes = 24.0 * n
+
+        def leg(name, xs, into=None):
+            out = {}
+            if into is None:
+                fn = lambda: out.__setitem__("r", sk.kernel_values(cfg, xs, k0=k0))
+            else:  # caller-provided (pinned) result arrays
+                fn = lambda: out.__setitem__("r", sk.kernel_values_into(cfg, xs, k0, into[0], into[1]))
+            dth = timed(fn, hsteps, hwarm, nofence) / hsteps
+            tm = sk.host_timing(cfg)
+            legs[name] = {"ms_per_step": 1e3 * dth, "value": xs.size / dth, "GB/s_effective": io_bytes / dth / 1e9,
+                          "split_ms": {k: round(v, 4) for k, v in tm.items()}, "unique_lags": cfg.last_stats()["n_unique"]}
+            return out["r"]
+
+        hv, _ = leg("sorted", rs)
+        host_err = float(np.abs(hv - ks).max() / abs(k0))
+        prng = np.random.default_rng(7)
+        perm = prng.permutation(n)
+        xs_p = np.ascontiguousarray(np.r_[rs[perm[: n - n // 10]], rs[perm[: n // 10]]])  # 10 % duplicates, shuffled
+        prng.shuffle(xs_p)
+        pv, _ = leg("permuted_with_duplicates", xs_p)
+        truth_p = k0 * (1 + 2 * np.pi * xs_p) * np.exp(-2 * np.pi * xs_p) if args.workload == "C2" else None
+        px, pk, pe = sk.pinned_empty(n), sk.pinned_empty(n), sk.pinned_empty(n)
+        px[:] = rs
+        leg("sorted_pinned_arrays", px, into=(pk, pe))
+        host = {"what": "sk_kernel_values: host array in, two host arrays out (src/adaptive.jl:95-108), %d steps" % hsteps,
+                "ms_per_step": legs["sorted"]["ms_per_step"], "value": legs["sorted"]["value"], "unit": "r-targets/s",
+                "GB/s_effective": legs["sorted"]["GB/s_effective"], "legs": legs,
+                "max_abs_diff_vs_device_leg_over_k0": host_err,
+                "permuted_max_rel_err_vs_closed_form": (float(np.abs(pv - truth_p).max() / abs(k0))
+                                                        if truth_p is not None else None),
+                "pinned_leg_max_abs_diff_over_k0": float(np.abs(pk - ks).max() / abs(k0)),
+                "copy_threads": int(os.environ.get("SK_COPY_THREADS", "8"))}
 
     # ---- per-kernel roofline from HIP events on the kernels' own stream (separate, untimed passes)
     cfg.profile(True)
@@ -173,15 +252,14 @@ def main():
                 for f in ("total_ms", "launches", "active_items"):
                     acc[k][f] += kt[k][f]
     cfg.profile(False)
-    # dominant kernel: k_interp (39 % of device time in the rocprofv3 kernel stats, profiles/r01_c2_summary.txt; the
-    # HIP-event brackets add the launch gap to whichever kernel follows a host synchronisation, so the event totals
-    # of k_interp and the fused k_spread are too close to rank them reliably)
+    st = cfg.last_stats()
+    # dominant kernel: k_interp (largest share of device time in the rocprofv3 kernel stats, profiles/*_summary.txt;
+    # the HIP-event brackets add the launch gap to whichever kernel follows a host synchronisation, so the event
+    # totals of k_interp and the fused k_spread are too close to rank them reliably)
     dom = "interp" if acc.get("interp", {}).get("launches", 0) > 0 else max(acc, key=lambda k: acc[k]["total_ms"])
-    # algorithmic bytes per launch: interp/accum per active lag, gen/spread per panel
     M = cfg.quadspec[0] * cfg.quadspec[1]
     # interp per active lag and evaluation: read r (8) + confirmed sums (16, not on the very first panel), write the
     # optimistic sums (16); the final outputs (16) once per lag, when it retires  -> 40 B x sum_active per call
-    # (40*sum_active - 16*n_first + 16*n_first; DESIGN.md, Kernels)
     interp_bytes_total = 10 * 40.0 * st["sum_active"]  # over the 10 profiled calls
     rl = {}
     for k, v in acc.items():
@@ -207,22 +285,32 @@ def main():
     # HBM bytes per launch of the dominant kernel from the committed PMC summary of this round
     # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/profile_round.sh)
     traffic = None
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_%s_summary.json" % args.workload.lower())))
-        for kname, tv in pj.get("traffic", {}).items():
-            if ("k_" + dom) in kname:
-                traffic = tv["hbm_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    for rnd in (ROUND, "r01"):
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "%s_%s_summary.json" % (rnd, args.workload.lower()))))
+            for kname, tv in pj.get("traffic", {}).items():
+                if ("k_" + dom) in kname:
+                    traffic = tv["hbm_bytes_per_launch"]
+            if traffic is not None:
+                break
+        except Exception:
+            pass
+    floor = cfg.launch_floor()
     roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": rl[dom]["gbps"], "peak": peak, "unit": "GB/s",
                 "frac": rl[dom]["gbps"] / peak, "traffic": traffic, "avg_us": rl[dom]["avg_us"],
                 "algorithmic_bytes_per_launch": rl[dom]["bytes"],
                 "per_kernel": {k: {"avg_us": round(v["avg_us"], 3), "GB/s": round(v["gbps"], 1),
-                                   "launches_per_step": v["launches_per_step"]} for k, v in rl.items()}}
+                                   "launches_per_step": v["launches_per_step"]} for k, v in rl.items()},
+                # what a launch costs before it does any work, measured in this run with the same event brackets:
+                # an empty kernel, the fused spread launch reduced to its step-state prologue, k_interp reduced to
+                # its state loads (DESIGN.md "Launch floor")
+                "launch_floor_us": floor}
+    if "spread" in roofline["per_kernel"]:
+        roofline["per_kernel"]["spread"]["launch_floor_us"] = floor.get("spread_prologue_only")
     # whole-step view: algorithmic bytes per lag (24 + 40*abar + 48*M*Q/N) over the step time
     abar = st["sum_active"] / max(1, st["n_unique"])
     bytes_per_lag = 24.0 + 40.0 * abar + 48.0 * M * st["n_panels"] / max(1, n)
-    roofline["step_GB/s"] = bytes_per_lag * n / (ms_per_step * 1e-3) / 1e9
+    roofline["step_GB/s"] = bytes_per_lag * n / (1e3 * dt_local / args.steps * 1e-3) / 1e9
     roofline["step_frac"] = roofline["step_GB/s"] / peak
     roofline["bytes_per_lag"] = bytes_per_lag
 
@@ -231,6 +319,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import sk_oracle as o
+        ref_state, ref_found = reference_probe()
         ocfg = o.AdaptiveKernelConfig(getattr(o.SDF, kind)(*prm), use_nufft=True, **w["kw"])
         o.gauss_rules(ocfg.quadspec[0], ocfg.p)
         best, reps, oks = None, 0, None
@@ -250,9 +339,9 @@ def main():
         tdir = time.perf_counter() - tc
         if fast_ok:
             cpu = {"value": n / best, "unit": "r-targets/s", "cores": ocfg.nthreads, "kind": "port",
-                   "sample": "all %d lags, oracle with its CPU type-3 NUFFT (OpenMP), best of %d runs, %.2f s each; "
-                             "exact direct sums on %d of the lags: %.0f r-targets/s" % (n, reps, best, idx.size,
-                                                                                         idx.size / tdir),
+                   "sample": "all %d lags, host array in / host arrays out, oracle with its CPU type-3 NUFFT (OpenMP), best "
+                             "of %d runs, %.2f s each; exact direct sums on %d of the lags: %.0f r-targets/s" % (
+                                 n, reps, best, idx.size, idx.size / tdir),
                    "max_abs_diff_vs_gpu_over_k0": float(np.abs(oks - ks).max() / abs(k0)),
                    "direct_sum_sample_diff_vs_gpu_over_k0": float(np.abs(dks - ks[idx]).max() / abs(k0))}
         else:
@@ -260,18 +349,24 @@ def main():
                    "sample": "%d of the %d lags, oracle with exact direct Bessel sums (OpenMP; the oracle has no fast "
                              "Hankel transform), %.1f s" % (idx.size, n, tdir),
                    "max_abs_diff_vs_gpu_over_k0": float(np.abs(dks - ks[idx]).max() / abs(k0))}
+        cpu["reference"] = ref_state  # Julia + FINUFFT (README.md:38-48) on this box?
+        cpu["reference_probe"] = ref_found
+        if host is not None:  # like against like: both spans are host array -> host arrays
+            cpu["gpu_host_to_host_over_cpu"] = host["value"] / cpu["value"]
 
     if rank == 0:
         out = {"metric": "r-targets/sec at tol=%g" % w["kw"]["tol"], "value": value, "unit": "r-targets/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-               "scaling": "strong" if args.workload == "C4" else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "scaling": "strong" if args.workload == "C4" and world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic",
                "config": {"workload": args.workload + ": " + w["desc"], "lags_per_gpu": n,
-                          "sharding": "r-set strided over ranks, K(0) all-reduce at set-up only",
+                          "sharding": "r-set %s over ranks, K(0) all-reduce at set-up only" % args.shard,
                           "nufft_width": cfg.nufft_width},
                "max_rel_err_vs_closed_form": max_rel_err,
                "panels": {"outer": st["n_outer"], "nufft_pairs": st["n_panels"], "abar": abar,
                           "steps_launched": st["n_steps_launched"], "host_syncs": st["n_syncs"]},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "rccl_ranks": world if dist is not None else 0, "per_rank": per_rank,
+               "host_to_host": host, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

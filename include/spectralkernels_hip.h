@@ -97,12 +97,42 @@ int sk_config_rules(const sk_config* cfg, int which, double* no1, double* wt1, d
 /* compute_k0(config) -- src/adaptive.jl:74-91.  Host quadrature (adaptive Gauss-Kronrod). */
 int sk_compute_k0(sk_config* cfg, double* k0);
 
+/* Statistics of the last sk_kernel_values* call on this config (panel schedule). */
+typedef struct {
+  int64_t n_unique;      /* targets after dedup */
+  int64_t n_outer;       /* outer panels marched (src/adaptive.jl:149 loop iterations) */
+  int64_t n_panels;      /* (sub)panel evaluations = NUFFT pairs Q */
+  int64_t n_accepted;
+  int64_t sum_active;    /* sum over panel evaluations of active targets (a-bar * N) */
+  int64_t n_steps_launched; /* device steps enqueued incl. speculative ones */
+  int64_t n_syncs;       /* host<->device synchronisations */
+  double last_b;         /* upper end of the last panel */
+} sk_stats;
+int sk_last_stats(const sk_config* cfg, sk_stats* out);
+
 /* kernel_values(config, xs; k0, param_derivative) -- src/adaptive.jl:95-108.
  * xs: host array, any order, duplicates allowed, entries >= 0.  vals/errs: caller-allocated
  * host arrays of length n, input order; errs is NaN at xs == 0 (src/adaptive.jl:137-144).
  * has_k0 == 0 computes k0 with sk_compute_k0 first. */
 int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int has_k0, int param_derivative,
                      double* vals_out, double* errs_out);
+/* Wall-clock split of the last sk_kernel_values call on this config, in ms: [0] staged upload of the lags
+ * (enqueue side), [1] march, [2] download into the caller's arrays, [3] whole call. */
+int sk_last_host_timing(const sk_config* cfg, double* ms4);
+
+/* Memory owned by the library's HIP runtime, so that a caller (the Julia shim, tests, bench.py) needs no HIP
+ * binding of its own.  sk_host_alloc returns PINNED host memory: arrays that live in it are copied by DMA
+ * directly, without the staging pass that pageable arrays need (sk_kernel_values detects this per pointer).
+ * sk_memcpy_* are synchronous; device < 0 = current device. */
+int sk_device_count(int* n);
+int sk_device_malloc(void** d_ptr, size_t bytes, int device);
+int sk_device_free(void* d_ptr);
+int sk_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
+int sk_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
+int sk_device_synchronize(int device);
+int sk_device_mem_info(size_t* free_bytes, size_t* total_bytes); /* current device */
+int sk_host_alloc(void** ptr, size_t bytes);
+int sk_host_free(void* ptr);
 
 /* Same computation on HBM-resident arrays: d_xs, d_vals, d_errs are device pointers on the
  * config's device; stream is a hipStream_t (NULL = default stream).  Any order / duplicates
@@ -119,6 +149,27 @@ int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double
  * with has_k0 = 1); vals_out / errs_out: ncfg x n, row c = config c in input order. */
 int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, const double* k0s,
                            const int* param_derivative, double* vals_out, double* errs_out);
+
+/* One process, several GPUs (the reference's kernel_values is one call on one host Vector,
+ * src/adaptive.jl:95-98): the sorted unique lag set is cut into contiguous blocks, one per device; every device
+ * holds a replica of the config and marches its own block (its panel widths follow its own largest lag,
+ * src/adaptive.jl:152) with no exchange after K(0), which is computed once and shared.  Each shard reads its
+ * block of `xs` and writes its block of vals/errs in place.  devices == NULL: devices 0..ndev-1.
+ * Same contract as sk_kernel_values (any order, duplicates allowed; results within tol of the single-device
+ * call -- the panel schedules of the shards differ). */
+typedef struct sk_sharded sk_sharded; /* opaque */
+int sk_sharded_create(sk_sharded** out, const sk_config_args* args, const int* devices, int ndev);
+void sk_sharded_destroy(sk_sharded* sh);
+int sk_sharded_count(const sk_sharded* sh);
+int sk_kernel_values_sharded(sk_sharded* sh, const double* xs, size_t n, double k0, int has_k0, int param_derivative,
+                             double* vals_out, double* errs_out);
+/* Last call, per shard: panel statistics, wall time (ms) and block [lo, hi) of the sorted unique set. */
+int sk_sharded_last(const sk_sharded* sh, int shard, sk_stats* st, double* ms, int64_t* lo, int64_t* hi);
+/* Test hook (CPU tier): shards whose device call is replaced by `fn` (same meaning as sk_kernel_values with
+ * has_k0 = 1 on the block) -- exercises the split / dedup / merge logic without a device. */
+typedef int (*sk_shard_fn)(int shard, const double* xs, size_t n, double k0, int param_derivative, double* vals,
+                           double* errs, void* ctx);
+int sk_sharded_create_injected(sk_sharded** out, int nshard, sk_shard_fn fn, void* ctx);
 
 /* Callers' side of the path: lags from point pairs, generated on the device so that an n-point set never
  * materialises its n(n-1)/2 lags on the host.
@@ -144,18 +195,6 @@ int sk_dense_cov_matrix_device(sk_config* cfg, const double* d_pts, size_t npts,
 int sk_panel_sums(sk_config* cfg, const double* nodes, const double* coef, size_t M, double lo, double hi,
                   const double* xs, size_t n, int method, double* out_re, double* out_im);
 
-/* Statistics of the last sk_kernel_values* call on this config (panel schedule). */
-typedef struct {
-  int64_t n_unique;      /* targets after dedup */
-  int64_t n_outer;       /* outer panels marched (src/adaptive.jl:149 loop iterations) */
-  int64_t n_panels;      /* (sub)panel evaluations = NUFFT pairs Q */
-  int64_t n_accepted;
-  int64_t sum_active;    /* sum over panel evaluations of active targets (a-bar * N) */
-  int64_t n_steps_launched; /* device steps enqueued incl. speculative ones */
-  int64_t n_syncs;       /* host<->device synchronisations */
-  double last_b;         /* upper end of the last panel */
-} sk_stats;
-int sk_last_stats(const sk_config* cfg, sk_stats* out);
 
 /* Per-kernel device timing of the hot path, measured with HIP events on the stream the kernels
  * are launched on.  Off by default (events add host overhead); when enabled every launch of the
@@ -168,6 +207,11 @@ typedef struct {
   int64_t launches[SK_K_COUNT];
   int64_t active_items[SK_K_COUNT]; /* summed work items: nodes (gen), grid points (spread, fft), active lags (interp), panels (advance) */
 } sk_kernel_times;
+/* What a launch costs before it does any work, in us, with the same event brackets: [0] an empty kernel on the
+ * fused spread launch's grid, [1] that launch reduced to its step-state prologue, [2] k_interp reduced to its state
+ * loads, [3] the empty kernel launched back to back (one bracket around `reps` launches, per launch).  Not to be
+ * called while another call on this config is in flight. */
+int sk_launch_floor(sk_config* cfg, int reps, double* us4);
 int sk_profile_enable(sk_config* cfg, int on);
 int sk_profile_read(const sk_config* cfg, sk_kernel_times* out);
 

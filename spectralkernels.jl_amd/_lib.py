@@ -10,6 +10,8 @@ SK_WARN_QUADSPEC = 100
 SDF_CALLBACK, SDF_MATERN, SDF_EXPONENTIAL, SDF_GAUSSIAN = 0, 1, 2, 3
 
 SDF_BATCH_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
+SHARD_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_double, C.c_int, C.POINTER(C.c_double),
+                       C.POINTER(C.c_double), C.c_void_p)
 
 
 class ConfigArgs(C.Structure):
@@ -63,8 +65,26 @@ def load():
     L.sk_dense_cov_matrix.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
     L.sk_dense_cov_matrix_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]
     L.sk_panel_sums.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_double, vp, C.c_size_t, C.c_int, vp, vp]
+    L.sk_last_host_timing.argtypes = [vp, dp]
+    L.sk_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.sk_device_malloc.argtypes = [C.POINTER(vp), C.c_size_t, C.c_int]
+    L.sk_device_free.argtypes = [vp]
+    L.sk_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+    L.sk_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+    L.sk_device_synchronize.argtypes = [C.c_int]
+    L.sk_device_mem_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.sk_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.sk_host_free.argtypes = [vp]
+    L.sk_sharded_create.argtypes = [C.POINTER(vp), C.POINTER(ConfigArgs), C.POINTER(C.c_int), C.c_int]
+    L.sk_sharded_create_injected.argtypes = [C.POINTER(vp), C.c_int, SHARD_FN, vp]
+    L.sk_sharded_destroy.argtypes = [vp]
+    L.sk_sharded_destroy.restype = None
+    L.sk_sharded_count.argtypes = [vp]
+    L.sk_kernel_values_sharded.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp]
+    L.sk_sharded_last.argtypes = [vp, C.c_int, C.POINTER(Stats), dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sk_last_stats.argtypes = [vp, C.POINTER(Stats)]
     L.sk_last_trace.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sk_launch_floor.argtypes = [vp, C.c_int, dp]
     L.sk_profile_enable.argtypes = [vp, C.c_int]
     L.sk_profile_read.argtypes = [vp, C.POINTER(KernelTimes)]
     L.sk_host_gauss_rule.argtypes = [C.c_int64, C.c_double, vp, vp]

@@ -151,6 +151,14 @@ class AdaptiveKernelConfig:
         """Bracket every kernel launch of the following calls with HIP events (see kernel_times)."""
         _check(L.load().sk_profile_enable(self._h, int(bool(on))))
 
+    def launch_floor(self, reps=20):
+        """us per launch before any work is done (sk_launch_floor): empty kernel, fused spread launch reduced to
+        its prologue, k_interp reduced to its state loads, empty kernel back to back."""
+        t = (C.c_double * 4)()
+        _check(L.load().sk_launch_floor(self._h, int(reps), t))
+        return dict(empty_kernel=round(t[0], 3), spread_prologue_only=round(t[1], 3), interp_state_loads_only=round(t[2], 3),
+                    empty_kernel_back_to_back=round(t[3], 3))
+
     def kernel_times(self):
         """{kernel: dict(total_ms, launches, active_items)} of the last profiled call."""
         kt = L.KernelTimes()
@@ -187,6 +195,18 @@ def kernel_values(config, xs, k0=None, param_derivative=False, verbose=False):
         for r in config.last_trace():
             print("\tsubpanel w in [%.2e, %.2e] %s with max error %.2e (%d lags)" % (
                 r["a"], r["b"], "converged" if r["accepted"] else "did not converge", r["max_err"], r["n_active"]))
+    return vals, errs
+
+
+def kernel_values_into(config, xs, k0, vals, errs, param_derivative=False):
+    """kernel_values writing into caller-provided float64 arrays (e.g. pinned_empty ones): no allocation, and no
+    staging copies when xs / vals / errs live in pinned memory."""
+    n = xs.size
+    assert xs.dtype == np.float64 and vals.dtype == np.float64 and errs.dtype == np.float64
+    assert xs.flags.c_contiguous and vals.flags.c_contiguous and errs.flags.c_contiguous and vals.size == n == errs.size
+    _check(L.load().sk_kernel_values(config._h, xs.ctypes.data_as(C.c_void_p), n, 0.0 if k0 is None else float(k0),
+                                     0 if k0 is None else 1, int(bool(param_derivative)),
+                                     vals.ctypes.data_as(C.c_void_p), errs.ctypes.data_as(C.c_void_p)))
     return vals, errs
 
 
@@ -264,3 +284,147 @@ def panel_sums(config, nodes, coef, lo, hi, xs, method="nufft"):
 
 def device_available():
     return bool(L.load().sk_device_available())
+
+
+def device_count():
+    n = C.c_int()
+    _check(L.load().sk_device_count(C.byref(n)))
+    return n.value
+
+
+class DeviceArray:
+    """n float64 in HBM, owned by the library's own HIP runtime (no torch / other HIP binding in the process)."""
+
+    def __init__(self, n, device=-1):
+        self.n, self.ptr = int(n), None
+        p = C.c_void_p()
+        _check(L.load().sk_device_malloc(C.byref(p), 8 * self.n, int(device)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_host(cls, a, device=-1):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        d = cls(a.size, device)
+        _check(L.load().sk_memcpy_h2d(C.c_void_p(d.ptr), a.ctypes.data_as(C.c_void_p), 8 * a.size))
+        return d
+
+    def to_host(self):
+        out = np.empty(self.n)
+        _check(L.load().sk_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), 8 * self.n))
+        return out
+
+    def free(self):
+        if self.ptr:
+            try:
+                L.load().sk_device_free(C.c_void_p(self.ptr))
+            except Exception:
+                pass
+            self.ptr = None
+
+    __del__ = free
+
+
+class _PinnedOwner:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            L.load().sk_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(n):
+    """float64 ndarray of length n in pinned host memory (sk_host_alloc): kernel_values copies such arrays by
+    DMA directly, without the staging pass pageable arrays need."""
+    n = int(n)
+    p = C.c_void_p()
+    _check(L.load().sk_host_alloc(C.byref(p), 8 * max(n, 1)))
+    buf = (C.c_double * max(n, 1)).from_address(p.value)
+    buf._sk_owner = _PinnedOwner(p.value)  # every ndarray view keeps `buf`, hence the allocation, alive
+    return np.frombuffer(buf, dtype=np.float64, count=n)
+
+
+def device_mem_info():
+    """(free, total) bytes of the current device."""
+    f, t = C.c_size_t(), C.c_size_t()
+    _check(L.load().sk_device_mem_info(C.byref(f), C.byref(t)))
+    return f.value, t.value
+
+
+def synchronize(device=-1):
+    _check(L.load().sk_device_synchronize(int(device)))
+
+
+def host_timing(config):
+    """Wall-clock split (ms) of the last kernel_values call: upload, march, download, total."""
+    t = (C.c_double * 4)()
+    _check(L.load().sk_last_host_timing(config._h, t))
+    return dict(upload_ms=t[0], march_ms=t[1], download_ms=t[2], total_ms=t[3])
+
+
+class ShardedKernelConfig:
+    """One process driving several GPUs: a replica of the config per device, the sorted unique lag set cut into
+    contiguous blocks (sk_sharded_create / sk_kernel_values_sharded).  `backend`: CPU-tier test hook replacing the
+    device call of a shard, callable(shard, xs, k0, param_derivative) -> (vals, errs)."""
+
+    def __init__(self, f=None, devices=None, n_devices=None, backend=None, n_shards=None, **kw):
+        self._h = None
+        lib = L.load()
+        h = C.c_void_p()
+        if backend is not None:
+            def _fn(shard, xp, n, k0, pd, vp, ep, ctx):
+                try:
+                    xs = np.ctypeslib.as_array(xp, shape=(n,)).copy()
+                    v, e = backend(shard, xs, k0, bool(pd))
+                    np.ctypeslib.as_array(vp, shape=(n,))[:] = v
+                    np.ctypeslib.as_array(ep, shape=(n,))[:] = e
+                    return 0
+                except Exception:  # reported as a shard failure
+                    return L.SK_EHIP
+            self._keep = L.SHARD_FN(_fn)
+            _check(lib.sk_sharded_create_injected(C.byref(h), int(n_shards), self._keep, None))
+        else:
+            kw.setdefault("convergence_criteria", "both")
+            args, self._keep, self.f = _make_args(
+                f, kw.get("df"), kw.get("dim", 1), kw.get("alpha", 0.0), kw.get("tol", 1e-8), kw.get("derivative", False),
+                kw.get("logw", False), kw["convergence_criteria"], kw.get("tail"), kw.get("quadspec", (2 ** 12, 2 ** 4)),
+                -1, kw.get("nufft_width", 0), kw.get("hankel_min_lags", 0))
+            self._args = args
+            if devices is None:
+                devices = list(range(n_devices if n_devices else device_count()))
+            dv = (C.c_int * len(devices))(*devices)
+            code = _check(lib.sk_sharded_create(C.byref(h), C.byref(args), dv, len(devices)))
+            if code == L.SK_WARN_QUADSPEC:
+                warnings.warn(L.last_error())
+        self._h = h
+        self.n_shards = lib.sk_sharded_count(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                L.load().sk_sharded_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def kernel_values(self, xs, k0=None, param_derivative=False):
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        n = xs.size
+        vals, errs = np.zeros(n), np.zeros(n)
+        _check(L.load().sk_kernel_values_sharded(self._h, xs.ctypes.data_as(C.c_void_p), n,
+                                                 0.0 if k0 is None else float(k0), 0 if k0 is None else 1,
+                                                 int(bool(param_derivative)), vals.ctypes.data_as(C.c_void_p),
+                                                 errs.ctypes.data_as(C.c_void_p)))
+        return vals, errs
+
+    def last(self):
+        """Per shard: dict(lo, hi, ms, stats) of the last call."""
+        out = []
+        for s in range(self.n_shards):
+            st, ms, lo, hi = L.Stats(), C.c_double(), C.c_int64(), C.c_int64()
+            _check(L.load().sk_sharded_last(self._h, s, C.byref(st), C.byref(ms), C.byref(lo), C.byref(hi)))
+            out.append(dict(lo=lo.value, hi=hi.value, ms=ms.value,
+                            stats={k: getattr(st, k) for k, _ in L.Stats._fields_}))
+        return out

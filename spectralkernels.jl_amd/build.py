@@ -1,31 +1,50 @@
-"""Builds libspectralkernels_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Builds libspectralkernels_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Each source is compiled to an object under spectralkernels.jl_amd/build/ (rebuilt when it or a header is newer),
+then linked; `--force` rebuilds everything."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["sk_api.cpp", "sk_kernels.hip", "sk_rules.cpp", "sk_tables.cpp", "sk_k0.cpp"]
-HEADERS = ["sk_device.h", "sk_internal.h", os.path.join("..", "..", "include", "spectralkernels_hip.h")]
+OBJ = os.path.join(HERE, "build")
+SOURCES = ["sk_api.cpp", "sk_hostio.cpp", "sk_shard.cpp", "sk_kernels.hip", "sk_rules.cpp", "sk_tables.cpp", "sk_k0.cpp"]
+HEADERS = ["sk_device.h", "sk_internal.h", "sk_config.h", os.path.join("..", "..", "include", "spectralkernels_hip.h")]
 LIB = os.path.join(HERE, "libspectralkernels_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-munsafe-fp-atomics", "-Wno-unused-value",
+         "-Wno-pass-failed"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
 
 
 def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-shared",
-           "-munsafe-fp-atomics", "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES] + ["-lrocfft"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = [f for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    hdr_t = max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
+    jobs = []
+    objs = []
+    for f in srcs:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, os.path.splitext(f)[0] + ".o")
+        objs.append(obj)
+        if force or _mtime(obj) < max(_mtime(src), hdr_t):
+            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _mtime(LIB) < max(_mtime(o) for o in objs):
+        run([hipcc, "--offload-arch=gfx950", "-fPIC", "-fopenmp", "-shared", "-o", LIB] + objs + ["-lrocfft"])
     return LIB
 
 

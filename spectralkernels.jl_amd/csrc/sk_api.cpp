@@ -7,12 +7,12 @@
 #include <cstdlib>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
-#include "sk_device.h"
-#include "sk_internal.h"
+#include "sk_config.h"
 
 namespace sk {
 
@@ -22,19 +22,6 @@ int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
-
-#define HIPCHK(expr)                                                                                  \
-  do {                                                                                                \
-    hipError_t e_ = (expr);                                                                           \
-    if (e_ != hipSuccess)                                                                             \
-      return fail(SK_EHIP, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);        \
-  } while (0)
-#define FFTCHK(expr)                                                                       \
-  do {                                                                                     \
-    rocfft_status s_ = (expr);                                                             \
-    if (s_ != rocfft_status_success)                                                       \
-      return fail(SK_EHIP, std::string("rocFFT error ") + std::to_string((int)s_) + " at " #expr); \
-  } while (0)
 
 static std::once_flag g_fft_once;
 
@@ -49,66 +36,6 @@ static int64_t next_smooth_even(int64_t n) {
 }
 
 }  // namespace sk
-
-using namespace sk;
-
-struct sk_config {
-  sk_config_args args;
-  int64_t m, k, M;
-  double p, c;
-  int device;
-  int warned;
-  SdfHost sdf, dsdf;
-  // host rules
-  std::vector<double> leg[4], jac[4];
-  EsTables tab;
-  // device
-  DevConst dc;
-  EsConst ec;
-  EsConst* d_ec = nullptr;
-  DevBuffers db;
-  std::vector<void*> owned;  // device allocations freed at destroy
-  rocfft_plan plan = nullptr;
-  rocfft_plan plan_seam = nullptr;  // sk_panel_sums
-  rocfft_execution_info info_seam = nullptr;
-  void* fft_work_seam = nullptr;
-  rocfft_plan plan_hk = nullptr;   // batch 2*hk_terms(w), Hankel path
-  void* fft_work_hk = nullptr;
-  rocfft_execution_info info_hk = nullptr;
-  double hk_a[kHkTerms], hk_a2[kHkTerms];  // a_k(nu) of the main order and of dim/2 (logw pass B)
-  rocfft_execution_info info = nullptr;
-  void* fft_work = nullptr;
-  double* d_fvals = nullptr;
-  // per-call workspace (grow only)
-  void* ws = nullptr;
-  size_t ws_bytes = 0;
-  double* d_io = nullptr;          // staging of sk_kernel_values (host arrays)
-  size_t io_bytes = 0;
-  double* h_io = nullptr;          // pinned host staging of the same entry (lags, values, errors)
-  size_t hio_bytes = 0;
-  double* d_lags = nullptr;        // values / errors staging of the pair entries (3 n doubles)
-  size_t lags_bytes = 0;
-  double* d_plags = nullptr;       // pairwise lags generated on the device
-  size_t pl_bytes = 0;
-  HostStatus* h_status = nullptr;  // pinned + device-mapped, written by k_advance
-  unsigned int seq = 0;
-  size_t trace_len = 0;
-  bool trace_valid = false;
-  long long* h_nuniq = nullptr;
-  hipStream_t own_stream = nullptr;
-  // last call
-  sk_stats stats;
-  std::vector<TraceRec> trace;
-  // callback scratch
-  std::vector<double> h_nodes, h_fvals, h_fvals2, h_dfvals;
-  // optional per-kernel event timing
-  int profile = 0;
-  std::vector<hipEvent_t> ev_pool;
-  size_t ev_used = 0;
-  struct EvRec { int kid; hipEvent_t a, b; };
-  std::vector<EvRec> ev_recs;
-  sk_kernel_times ktimes;
-};
 
 namespace sk {
 
@@ -376,7 +303,12 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         for (size_t q = 0; q < w.size(); ++q) hv[q] *= std::log(w[q]);
       }
     }
-    HIPCHK(hipMemcpyAsync(cfg->d_fvals, hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice, st));
+    // through a pinned buffer of its own per pass (the A and B passes of a logw panel are enqueued back to back)
+    const int slot = (g == SK_G_LOGB) ? 1 : 0;
+    if (!cfg->h_fvpin[slot])
+      HIPCHK(hipHostMalloc((void**)&cfg->h_fvpin[slot], sizeof(double) * 3 * (size_t)cfg->M, hipHostMallocDefault));
+    std::memcpy(cfg->h_fvpin[slot], hv.data(), sizeof(double) * hv.size());
+    HIPCHK(hipMemcpyAsync(cfg->d_fvals, cfg->h_fvpin[slot], sizeof(double) * hv.size(), hipMemcpyHostToDevice, st));
     return SK_OK;
   };
 
@@ -462,8 +394,8 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       if (hs->done) break;
       if (cb) {
         host_nodes(cfg, hs->pp, cfg->h_nodes);
-        double fb = cfg->sdf(hs->b);
-        HIPCHK(hipMemcpyAsync(&db.state[t & 1].fb, &fb, sizeof(double), hipMemcpyHostToDevice, st));
+        *cfg->h_scal = cfg->sdf(hs->b);  // pinned; the previous iteration's copy completed before its status block
+        HIPCHK(hipMemcpyAsync(&db.state[t & 1].fb, cfg->h_scal, sizeof(double), hipMemcpyHostToDevice, st));
       }
       launch_tail(cfg->dc, db, t & 1, st);
       mode = SK_MODE_ASIS;
@@ -540,7 +472,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
 }
 
 static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t n, double k0, double ks0, double* d_vals,
-                                     double* d_errs, hipStream_t st) {
+                                     double* d_errs, hipStream_t st, int order = SK_ORDER_UNKNOWN) {
   std::memset(&cfg->stats, 0, sizeof(cfg->stats));
   cfg->trace_len = 0;
   cfg->trace_valid = false;
@@ -551,17 +483,24 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   const size_t nscr = cfg->dc.logw ? 10 : 6;  // + 4 n raw panel sums of the logw passes
   int rc = ensure_ws(cfg, nscr * a8);
   if (rc) return rc;
-  // The input is checked for "strictly increasing, >= 0" on the device and the march starts
+  // Host-array entries have looked at the lags while staging them (sk_hostio.cpp) and say so in `order`.
+  // Otherwise the input is checked for "strictly increasing, >= 0" on the device and the march starts
   // speculatively on it as is; the flags come back with the first status block (no extra sync).
+  if (order == SK_ORDER_INVALID) return fail(SK_EINVAL, "lags must be non-negative and finite");
   cfg->stats.n_unique = (int64_t)n;
-  rc = run_core(cfg, d_xs, (long long)n, k0, ks0, d_vals, d_errs, (double*)cfg->ws, st, true);
-  const int unsorted = cfg->h_status->flags[0], invalid = cfg->h_status->flags[1] & 1;
-  if (cfg->h_status->flags[1] & 2) {
+  int unsorted = 1, invalid = 0;
+  if (order != SK_ORDER_UNSORTED) {
+    rc = run_core(cfg, d_xs, (long long)n, k0, ks0, d_vals, d_errs, (double*)cfg->ws, st, order == SK_ORDER_UNKNOWN);
+    if (order == SK_ORDER_SORTED) return rc;
+    unsorted = cfg->h_status->flags[0];
+    invalid = cfg->h_status->flags[1] & 1;
+  }
+  if (order == SK_ORDER_UNKNOWN && (cfg->h_status->flags[1] & 2)) {
     (void)hipStreamSynchronize(st);
     (void)hipMemsetAsync(cfg->db.flags, 0, 2 * sizeof(int), st);
     return fail(SK_EHIP, "internal error: inconsistent device state detected by a kernel guard");
   }
-  if (unsorted || invalid) {
+  if (order == SK_ORDER_UNKNOWN && (unsorted || invalid)) {
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMemsetAsync(cfg->db.flags, 0, 2 * sizeof(int), st));
     cfg->ev_recs.clear();
@@ -653,13 +592,16 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   }
   HIPCHK(hipSetDevice(dev));
   {
-    // eager module load on an idle device (see k_module_warmup)
-    static std::once_flag warm;
-    std::call_once(warm, [] {
+    // eager module load on an idle device, once per device (see k_module_warmup)
+    static std::mutex warm_mu;
+    static unsigned long long warmed = 0ull;
+    std::lock_guard<std::mutex> lk(warm_mu);
+    if (dev < 64 && !(warmed >> dev & 1ull)) {
       (void)hipDeviceSynchronize();
       launch_module_warmup(nullptr);
       (void)hipDeviceSynchronize();
-    });
+      warmed |= 1ull << dev;
+    }
   }
   sk_config* cfg = new sk_config();
   cfg->args = *args;
@@ -783,7 +725,8 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
 #undef DA
   if (hipHostMalloc((void**)&cfg->h_status, sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&db.host_status, cfg->h_status, 0) != hipSuccess ||
-      hipHostMalloc((void**)&cfg->h_nuniq, sizeof(long long)) != hipSuccess) {
+      hipHostMalloc((void**)&cfg->h_nuniq, sizeof(long long)) != hipSuccess ||
+      hipHostMalloc((void**)&cfg->h_scal, 8 * sizeof(double)) != hipSuccess) {
     sk_config_destroy(cfg);
     return fail(SK_EHIP, "hipHostMalloc failed");
   }
@@ -892,11 +835,17 @@ void sk_config_destroy(sk_config* cfg) {
   for (void* p : cfg->owned) hipFree(p);
   if (cfg->ws) hipFree(cfg->ws);
   if (cfg->d_io) hipFree(cfg->d_io);
-  if (cfg->h_io) hipHostFree(cfg->h_io);
+  if (cfg->h_in) hipHostFree(cfg->h_in);
+  if (cfg->h_out) hipHostFree(cfg->h_out);
+  if (cfg->d_aux) hipFree(cfg->d_aux);
+  for (hipEvent_t e : cfg->cp_events) hipEventDestroy(e);
   if (cfg->d_lags) hipFree(cfg->d_lags);
   if (cfg->d_plags) hipFree(cfg->d_plags);
   if (cfg->h_status) hipHostFree(cfg->h_status);
   if (cfg->h_nuniq) hipHostFree(cfg->h_nuniq);
+  if (cfg->h_scal) hipHostFree(cfg->h_scal);
+  for (double* q : cfg->h_fvpin)
+    if (q) hipHostFree(q);
   if (cfg->own_stream) hipStreamDestroy(cfg->own_stream);
   for (hipEvent_t e : cfg->ev_pool) hipEventDestroy(e);
   delete cfg;
@@ -928,71 +877,37 @@ int sk_compute_k0(sk_config* cfg, double* k0) {
   return SK_OK;
 }
 
-int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double k0, int param_derivative, double* d_vals,
-                            double* d_errs, void* stream) {
-  if (!cfg) return fail(SK_EINVAL, "null config");
+static int kernel_values_device_order(sk_config* cfg, const double* d_xs, size_t n, double k0, int param_derivative,
+                                      double* d_vals, double* d_errs, hipStream_t st, int order) {
   double ks0 = k0;  // src/adaptive.jl:134-145
   if (cfg->args.derivative) ks0 = 0.0;
   else if (param_derivative) {
     int rc = sk_compute_k0(cfg, &ks0);
     if (rc) return rc;
   }
-  hipStream_t st = stream ? (hipStream_t)stream : cfg->own_stream;
-  return kernel_values_device_impl(cfg, d_xs, n, k0, ks0, d_vals, d_errs, st);
+  return kernel_values_device_impl(cfg, d_xs, n, k0, ks0, d_vals, d_errs, st, order);
 }
 
-// Host <-> device copies of large host arrays through a pinned staging buffer filled / drained by several host
-// threads: a pageable hipMemcpy of 24 MB costs ~3.5 ms on this stack (single-threaded staging inside the
-// runtime); the same bytes take ~1 ms as parallel memcpy + DMA from / to pinned memory.
-static const size_t kPinnedMin = (size_t)1 << 15;  // doubles; smaller arrays are copied directly
-static void par_copy(double* dst, const double* src, size_t cnt) {
-  const long long chunks = (long long)((cnt + 65535) / 65536);
-#pragma omp parallel for schedule(static) num_threads(8)
-  for (long long c = 0; c < chunks; ++c) {
-    const size_t lo = (size_t)c * 65536, len = cnt - lo < 65536 ? cnt - lo : 65536;
-    std::memcpy(dst + lo, src + lo, len * sizeof(double));
-  }
+int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double k0, int param_derivative, double* d_vals,
+                            double* d_errs, void* stream) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  hipStream_t st = stream ? (hipStream_t)stream : cfg->own_stream;
+  return kernel_values_device_order(cfg, d_xs, n, k0, param_derivative, d_vals, d_errs, st, SK_ORDER_UNKNOWN);
 }
-static int ensure_pinned(sk_config* cfg, size_t doubles) {
-  if (doubles * sizeof(double) <= cfg->hio_bytes) return SK_OK;
-  if (cfg->h_io) HIPCHK(hipHostFree(cfg->h_io));
-  cfg->h_io = nullptr;
-  cfg->hio_bytes = 0;
-  const size_t bytes = doubles * sizeof(double) + doubles * sizeof(double) / 4;
-  HIPCHK(hipHostMalloc((void**)&cfg->h_io, bytes, hipHostMallocDefault));
-  cfg->hio_bytes = bytes;
+
+// grow-only device buffers
+static int ensure_dev(void** buf, size_t* have, size_t bytes) {
+  if (bytes <= *have) return SK_OK;
+  if (*buf) HIPCHK(hipFree(*buf));
+  *buf = nullptr;
+  *have = 0;
+  HIPCHK(hipMalloc(buf, bytes + bytes / 4));
+  *have = bytes + bytes / 4;
   return SK_OK;
 }
-// device -> host, synchronous on `st`
-static int d2h_doubles(sk_config* cfg, double* dst, const double* d_src, size_t cnt, hipStream_t st) {
-  if (cnt < kPinnedMin) {
-    if (hipMemcpyAsync(dst, d_src, cnt * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-      return fail(SK_EHIP, "D2H copy failed");
-    return SK_OK;
-  }
-  int rc = ensure_pinned(cfg, cnt);
-  if (rc) return rc;
-  if (hipMemcpyAsync(cfg->h_io, d_src, cnt * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipStreamSynchronize(st) != hipSuccess)
-    return fail(SK_EHIP, "D2H copy failed");
-  par_copy(dst, cfg->h_io, cnt);
-  return SK_OK;
-}
-// host -> device; returns after the copy has been enqueued AND the staging buffer may be reused
-static int h2d_doubles(sk_config* cfg, double* d_dst, const double* src, size_t cnt, hipStream_t st) {
-  if (cnt < kPinnedMin) {
-    if (hipMemcpyAsync(d_dst, src, cnt * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
-      return fail(SK_EHIP, "H2D copy failed");
-    return SK_OK;
-  }
-  int rc = ensure_pinned(cfg, cnt);
-  if (rc) return rc;
-  par_copy(cfg->h_io, src, cnt);
-  if (hipMemcpyAsync(d_dst, cfg->h_io, cnt * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipStreamSynchronize(st) != hipSuccess)
-    return fail(SK_EHIP, "H2D copy failed");
-  return SK_OK;
+
+static double ms_since(const std::chrono::steady_clock::time_point& t0) {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int has_k0, int param_derivative,
@@ -1004,21 +919,31 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
   }
   if (n == 0) return SK_OK;
   HIPCHK(hipSetDevice(cfg->device));
+  const auto t0 = std::chrono::steady_clock::now();
   // grow-only device staging buffer of the host-array entry (lags, values, errors)
-  if (3 * n * sizeof(double) > cfg->io_bytes) {
-    if (cfg->d_io) HIPCHK(hipFree(cfg->d_io));
-    cfg->d_io = nullptr;
-    cfg->io_bytes = 0;
-    HIPCHK(hipMalloc((void**)&cfg->d_io, 3 * n * sizeof(double) + 3 * n * sizeof(double) / 4));
-    cfg->io_bytes = 3 * n * sizeof(double) + 3 * n * sizeof(double) / 4;
-  }
+  int rc = ensure_dev((void**)&cfg->d_io, &cfg->io_bytes, 3 * n * sizeof(double));
+  if (rc) return rc;
   double* d = cfg->d_io;
   hipStream_t st = cfg->own_stream;
-  int rc = h2d_doubles(cfg, d, xs, n, st);
-  if (!rc) rc = sk_kernel_values_device(cfg, d, n, k0, param_derivative, d + n, d + 2 * n, st);
-  if (!rc) rc = d2h_doubles(cfg, vals_out, d + n, n, st);
-  if (!rc) rc = d2h_doubles(cfg, errs_out, d + 2 * n, n, st);
+  int order = SK_ORDER_UNKNOWN;
+  rc = h2d_doubles(cfg, d, xs, n, st, &order);
+  if (rc) return rc;
+  const double t_up = ms_since(t0);
+  rc = kernel_values_device_order(cfg, d, n, k0, param_derivative, d + n, d + 2 * n, st, order);
+  const double t_march = ms_since(t0);
+  if (!rc) rc = d2h_doubles2(cfg, vals_out, errs_out, d + n, n, st);
+  const double t_all = ms_since(t0);
+  cfg->host_timing[0] = t_up;
+  cfg->host_timing[1] = t_march - t_up;
+  cfg->host_timing[2] = t_all - t_march;
+  cfg->host_timing[3] = t_all;
   return rc;
+}
+
+int sk_last_host_timing(const sk_config* cfg, double* ms4) {
+  if (!cfg || !ms4) return fail(SK_EINVAL, "null argument");
+  for (int i = 0; i < 4; ++i) ms4[i] = cfg->host_timing[i];
+  return SK_OK;
 }
 
 int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, const double* k0s,
@@ -1031,46 +956,51 @@ int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs
   sk_config* c0 = cfgs[0];
   HIPCHK(hipSetDevice(c0->device));
   hipStream_t st = c0->own_stream;
-  // device buffers of this call: lags, sorted unique lags, inverse map, per-config unique results and gathered
-  // results, sort scratch
+  // device buffers of this call (grow-only, owned by the first config): lags, sorted unique lags, inverse map,
+  // per-config unique results and gathered results (values and errors adjacent), sort scratch
   const size_t a8 = ((n * 8 + 255) / 256) * 256;
   const size_t tb = sort_unique_temp_bytes((long long)n);
-  char* buf = nullptr;
-  HIPCHK(hipMalloc((void**)&buf, 7 * a8 + tb + 512));
-  auto done = [&](int rc) {
-    (void)hipStreamSynchronize(st);
-    (void)hipFree(buf);
-    return rc;
-  };
+  int rc = ensure_dev(&c0->d_aux, &c0->aux_bytes, 7 * a8 + tb + 512);
+  if (rc) return rc;
+  char* buf = (char*)c0->d_aux;
   double* d_xs = (double*)buf;
   double* uxs = (double*)(buf + a8);
   long long* inv = (long long*)(buf + 2 * a8);
   double* ks = (double*)(buf + 3 * a8);
   double* errs = (double*)(buf + 4 * a8);
-  double* gk = (double*)(buf + 5 * a8);
-  double* ge = (double*)(buf + 6 * a8);
+  double* gk = (double*)(buf + 5 * a8);      // gathered values, then (n doubles later) gathered errors
+  double* ge = gk + n;
   long long* d_nu = (long long*)(buf + 7 * a8);
   void* tmp = buf + 7 * a8 + 256;
-  {
-    int rc = h2d_doubles(c0, d_xs, xs, n, st);
-    if (rc) return done(rc);
+  int order = SK_ORDER_UNKNOWN;
+  rc = h2d_doubles(c0, d_xs, xs, n, st, &order);
+  if (rc) return rc;
+  if (order == SK_ORDER_INVALID) return fail(SK_EINVAL, "lags must be non-negative and finite");
+  // src/adaptive.jl:99-120 once for all configs: unique + sort (skipped for strictly increasing input; pinned
+  // input of unknown order is sorted, which is harmless)
+  long long nu = (long long)n;
+  const bool sorted = (order == SK_ORDER_SORTED);
+  if (!sorted) {
+    sort_unique(d_xs, (long long)n, uxs, inv, d_nu, tmp, tb, st);
+    if (hipMemcpyAsync(c0->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return fail(SK_EHIP, "sort failed");
+    nu = *c0->h_nuniq;
   }
-  // src/adaptive.jl:99-120 once for all configs: unique + sort (the check for invalid lags is the first march's)
-  sort_unique(d_xs, (long long)n, uxs, inv, d_nu, tmp, tb, st);
-  if (hipMemcpyAsync(c0->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipStreamSynchronize(st) != hipSuccess)
-    return done(fail(SK_EHIP, "sort failed"));
-  const long long nu = *c0->h_nuniq;
   for (size_t c = 0; c < ncfg; ++c) {
-    int rc = sk_kernel_values_device(cfgs[c], uxs, (size_t)nu, k0s[c], param_derivative ? param_derivative[c] : 0, ks, errs,
-                                     st);
-    if (rc) return done(rc);
-    launch_gather(ks, errs, inv, (long long)n, gk, ge, st);
-    rc = d2h_doubles(c0, vals_out + c * n, gk, n, st);
-    if (!rc) rc = d2h_doubles(c0, errs_out + c * n, ge, n, st);
-    if (rc) return done(rc);
+    const int pd = param_derivative ? param_derivative[c] : 0;
+    if (sorted) {
+      rc = kernel_values_device_order(cfgs[c], d_xs, n, k0s[c], pd, gk, ge, st, SK_ORDER_SORTED);
+    } else {
+      // (sorted and unique by construction; the device check of the first march still catches invalid lags)
+      rc = kernel_values_device_order(cfgs[c], uxs, (size_t)nu, k0s[c], pd, ks, errs, st,
+                                      order == SK_ORDER_UNSORTED ? SK_ORDER_SORTED : SK_ORDER_UNKNOWN);
+      if (!rc) launch_gather(ks, errs, inv, (long long)n, gk, ge, st);
+    }
+    if (!rc) rc = d2h_doubles2(c0, vals_out + c * n, errs_out + c * n, gk, n, st);
+    if (rc) return rc;
   }
-  return done(SK_OK);
+  return SK_OK;
 }
 
 // grow-only buffer of 3 n doubles: lags, values, errors of the pair entries
@@ -1124,23 +1054,21 @@ int sk_kernel_values_pairs(sk_config* cfg, const double* pts, size_t npts, int p
   int rc = ensure_lags(cfg, n);
   if (rc) return rc;
   hipStream_t st = cfg->own_stream;
-  double* d_pts = nullptr;
-  int64_t* d_pairs = nullptr;
-  HIPCHK(hipMalloc((void**)&d_pts, npts * pdim * sizeof(double)));
-  if (pairs && hipMalloc((void**)&d_pairs, 2 * npairs * sizeof(int64_t)) != hipSuccess) {
-    (void)hipFree(d_pts);
-    return fail(SK_EHIP, "hipMalloc(pairs) failed");
+  // points and index pairs in the config's grow-only scratch (staged uploads: no pageable asynchronous copies)
+  const size_t pts_d = npts * (size_t)pdim, pts_b = ((pts_d * 8 + 255) / 256) * 256;
+  rc = ensure_dev(&cfg->d_aux, &cfg->aux_bytes, pts_b + (pairs ? 2 * npairs * sizeof(int64_t) : 0));
+  if (rc) return rc;
+  double* d_pts = (double*)cfg->d_aux;
+  int64_t* d_pairs = pairs ? (int64_t*)((char*)cfg->d_aux + pts_b) : nullptr;
+  rc = h2d_doubles(cfg, d_pts, pts, pts_d, st, nullptr);
+  if (!rc && pairs) {
+    // the staging buffer is reused by the second upload: the first one must have left it
+    if (hipStreamSynchronize(st) != hipSuccess) rc = fail(SK_EHIP, "stream synchronisation failed");
+    if (!rc) rc = h2d_doubles(cfg, (double*)d_pairs, (const double*)pairs, 2 * npairs, st, nullptr);  // 8-byte words
   }
-  if (hipMemcpyAsync(d_pts, pts, npts * pdim * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
-      (pairs && hipMemcpyAsync(d_pairs, pairs, 2 * npairs * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess))
-    rc = fail(SK_EHIP, "H2D copy failed");
   double* d = cfg->d_lags;
   if (!rc) rc = sk_kernel_values_pairs_device(cfg, d_pts, npts, pdim, d_pairs, npairs, k0, param_derivative, d + n, d + 2 * n, st);
-  if (!rc) rc = d2h_doubles(cfg, vals_out, d + n, n, st);
-  if (!rc) rc = d2h_doubles(cfg, errs_out, d + 2 * n, n, st);
-  if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(SK_EHIP, "stream synchronisation failed");
-  (void)hipFree(d_pts);
-  if (d_pairs) (void)hipFree(d_pairs);
+  if (!rc) rc = d2h_doubles2(cfg, vals_out, errs_out, d + n, n, st);
   return rc;
 }
 
@@ -1168,19 +1096,14 @@ int sk_dense_cov_matrix(sk_config* cfg, const double* pts, size_t npts, int pdim
   if (pdim < 1 || npts < 1) return fail(SK_EINVAL, "need at least one point and pdim >= 1");
   HIPCHK(hipSetDevice(cfg->device));
   hipStream_t st = cfg->own_stream;
-  double *d_pts = nullptr, *d_out = nullptr;
-  HIPCHK(hipMalloc((void**)&d_pts, npts * pdim * sizeof(double)));
-  if (hipMalloc((void**)&d_out, npts * npts * sizeof(double)) != hipSuccess) {
-    (void)hipFree(d_pts);
-    return fail(SK_EHIP, "hipMalloc(matrix) failed");
-  }
-  int rc = SK_OK;
-  if (hipMemcpyAsync(d_pts, pts, npts * pdim * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
-    rc = fail(SK_EHIP, "H2D copy failed");
+  const size_t pts_d = npts * (size_t)pdim, pts_b = ((pts_d * 8 + 255) / 256) * 256;
+  int rc = ensure_dev(&cfg->d_aux, &cfg->aux_bytes, pts_b + npts * npts * sizeof(double));
+  if (rc) return rc;
+  double* d_pts = (double*)cfg->d_aux;
+  double* d_out = (double*)((char*)cfg->d_aux + pts_b);
+  rc = h2d_doubles(cfg, d_pts, pts, pts_d, st, nullptr);
   if (!rc) rc = sk_dense_cov_matrix_device(cfg, d_pts, npts, pdim, d_out, st);
   if (!rc) rc = d2h_doubles(cfg, out, d_out, npts * npts, st);
-  (void)hipFree(d_pts);
-  (void)hipFree(d_out);
   return rc;
 }
 
@@ -1201,9 +1124,10 @@ int sk_panel_sums(sk_config* cfg, const double* nodes, const double* coef, size_
     hipFree(d_nodes);
     return code;
   };
-  if (hipMemcpyAsync(d_nodes, nodes, M * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(d_coef, coef, M * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(d_xs, xs, n * 8, hipMemcpyHostToDevice, st) != hipSuccess)
+  // test seam: plain synchronous copies (own_stream is a blocking stream, ordered behind them)
+  if (hipMemcpy(d_nodes, nodes, M * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_coef, coef, M * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_xs, xs, n * 8, hipMemcpyHostToDevice) != hipSuccess)
     return done(fail(SK_EHIP, "H2D copy failed"));
   if (method == 1) {
     launch_direct(d_nodes, d_coef, (int64_t)M, d_xs, (int64_t)n, d_re, d_im, st);
@@ -1236,12 +1160,56 @@ int sk_panel_sums(sk_config* cfg, const double* nodes, const double* coef, size_
     }
     launch_seam_interp(dc, cfg->d_ec, cfg->db.fft, d_xs, (int64_t)n, Cx, r_hi, tau, theta_scale, d_re, d_im, st);
   }
-  if (hipMemcpyAsync(out_re, d_re, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipMemcpyAsync(out_im, d_im, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipStreamSynchronize(st) != hipSuccess)
+  if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(out_re, d_re, n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(out_im, d_im, n * 8, hipMemcpyDeviceToHost) != hipSuccess)
     return done(fail(SK_EHIP, "D2H copy failed"));
   if (hipGetLastError() != hipSuccess) return done(fail(SK_EHIP, "kernel launch failed"));
   return done(SK_OK);
+}
+
+// What a launch costs before it does any work (bench.py "launch_floor_us"), with the same event brackets as the
+// per-kernel times: [0] an empty kernel on the fused spread launch's grid, [1] that launch reduced to its
+// step-state prologue (the state says "done": every workgroup derives the state and exits), [2] k_interp reduced
+// to its state loads, [3] the empty kernel launched back to back (one bracket around `reps` launches, per launch).
+int sk_launch_floor(sk_config* cfg, int reps, double* us4) {
+  if (!cfg || !us4 || reps < 1) return fail(SK_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(cfg->device));
+  hipStream_t st = cfg->own_stream;
+  HIPCHK(hipStreamSynchronize(st));
+  DevState fin;
+  std::memset(&fin, 0, sizeof(fin));
+  fin.done = 1;
+  fin.rhi_for = -1;
+  HIPCHK(hipMemcpy(&cfg->db.state[0], &fin, sizeof(fin), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(&cfg->db.state[1], &fin, sizeof(fin), hipMemcpyHostToDevice));
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  const unsigned grid = launch_genspread_grid(cfg->dc);
+  auto bracket = [&](int which, int count) -> double {
+    (void)hipEventRecord(a, st);
+    for (int q = 0; q < count; ++q) {
+      if (which == 0) launch_empty(grid, st);
+      else if (which == 1) launch_genspread(cfg->dc, cfg->d_ec, cfg->db, SK_MODE_ASIS, 0, 0, 0.0, 0.0, st);
+      else launch_interp(cfg->dc, cfg->d_ec, cfg->db, 0, 1000000, SK_RAW_NONE, st);
+    }
+    (void)hipEventRecord(b, st);
+    (void)hipEventSynchronize(b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return 1e3 * ms;
+  };
+  for (int which = 0; which < 3; ++which) {
+    bracket(which, 2);  // warm
+    double sum = 0.0;
+    for (int r = 0; r < reps; ++r) sum += bracket(which, 1);
+    us4[which] = sum / reps;
+  }
+  us4[3] = bracket(0, reps) / reps;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  HIPCHK(hipGetLastError());
+  return SK_OK;
 }
 
 int sk_profile_enable(sk_config* cfg, int on) {

@@ -1,0 +1,103 @@
+// sk_config.h -- the config handle behind the C ABI (private to the library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+#include <atomic>
+#include <string>
+#include <vector>
+#include "sk_device.h"
+#include "sk_internal.h"
+
+#define HIPCHK(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return sk::fail(SK_EHIP, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);    \
+  } while (0)
+#define FFTCHK(expr)                                                                       \
+  do {                                                                                     \
+    rocfft_status s_ = (expr);                                                             \
+    if (s_ != rocfft_status_success)                                                       \
+      return sk::fail(SK_EHIP, std::string("rocFFT error ") + std::to_string((int)s_) + " at " #expr); \
+  } while (0)
+
+using namespace sk;
+
+struct sk_config {
+  sk_config_args args;
+  int64_t m, k, M;
+  double p, c;
+  int device;
+  int warned;
+  SdfHost sdf, dsdf;
+  // host rules
+  std::vector<double> leg[4], jac[4];
+  EsTables tab;
+  // device
+  DevConst dc;
+  EsConst ec;
+  EsConst* d_ec = nullptr;
+  DevBuffers db;
+  std::vector<void*> owned;  // device allocations freed at destroy
+  rocfft_plan plan = nullptr;
+  rocfft_plan plan_seam = nullptr;  // sk_panel_sums
+  rocfft_execution_info info_seam = nullptr;
+  void* fft_work_seam = nullptr;
+  rocfft_plan plan_hk = nullptr;   // batch 2*hk_terms(w), Hankel path
+  void* fft_work_hk = nullptr;
+  rocfft_execution_info info_hk = nullptr;
+  double hk_a[kHkTerms], hk_a2[kHkTerms];  // a_k(nu) of the main order and of dim/2 (logw pass B)
+  rocfft_execution_info info = nullptr;
+  void* fft_work = nullptr;
+  double* d_fvals = nullptr;
+  // per-call workspace (grow only)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  double* d_io = nullptr;          // staging of sk_kernel_values (host arrays)
+  size_t io_bytes = 0;
+  // pinned host staging of the host-array entries (sk_hostio.cpp): lags in, values and error estimates out
+  double* h_in = nullptr;
+  size_t hin_bytes = 0;
+  double* h_out = nullptr;
+  size_t hout_bytes = 0;
+  std::vector<std::atomic<int>> chunk_done;  // threads done with chunk c of the staged upload
+  std::vector<hipEvent_t> cp_events;         // one per download chunk
+  double host_timing[4] = {0, 0, 0, 0};      // last sk_kernel_values call: upload, march, download, total (ms)
+  // grow-only device scratch of the multi / pairs / dense entries (points, index pairs, per-config results)
+  void* d_aux = nullptr;
+  size_t aux_bytes = 0;
+  double* d_lags = nullptr;        // values / errors staging of the pair entries (3 n doubles)
+  size_t lags_bytes = 0;
+  double* d_plags = nullptr;       // pairwise lags generated on the device
+  size_t pl_bytes = 0;
+  HostStatus* h_status = nullptr;  // pinned + device-mapped, written by k_advance
+  unsigned int seq = 0;
+  size_t trace_len = 0;
+  bool trace_valid = false;
+  long long* h_nuniq = nullptr;
+  double* h_scal = nullptr;        // pinned scalars handed to small asynchronous uploads
+  double* h_fvpin[2] = {nullptr, nullptr};  // callback SDFs: pinned copies of the integrand values of a pass
+  hipStream_t own_stream = nullptr;
+  // last call
+  sk_stats stats;
+  std::vector<TraceRec> trace;
+  // callback scratch
+  std::vector<double> h_nodes, h_fvals, h_fvals2, h_dfvals;
+  // optional per-kernel event timing
+  int profile = 0;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  struct EvRec { int kid; hipEvent_t a, b; };
+  std::vector<EvRec> ev_recs;
+  sk_kernel_times ktimes;
+};
+
+namespace sk {
+// what the upload pass found out about the lags (src/adaptive.jl:99,113): strictly increasing (hence unique), not,
+// or containing a negative / NaN entry; UNKNOWN (pinned or device-resident input) leaves the check to the device
+enum { SK_ORDER_UNKNOWN = 0, SK_ORDER_SORTED = 1, SK_ORDER_UNSORTED = 2, SK_ORDER_INVALID = 3 };
+// sk_hostio.cpp: transfers between caller-owned host arrays and the device (pinned staging, chunked and overlapped)
+int h2d_doubles(sk_config* cfg, double* d_dst, const double* src, size_t cnt, hipStream_t st, int* order);
+int d2h_doubles2(sk_config* cfg, double* dst_a, double* dst_b, const double* d_src, size_t cnt_each, hipStream_t st);
+int d2h_doubles(sk_config* cfg, double* dst, const double* d_src, size_t cnt, hipStream_t st);
+}  // namespace sk

@@ -170,6 +170,8 @@ struct DevBuffers {
 
 // launchers (sk_kernels.hip)
 void launch_module_warmup(hipStream_t st);
+void launch_empty(unsigned grid, hipStream_t st);
+unsigned launch_genspread_grid(const DevConst& dc);
 void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);  // callback SDFs, dim > 1
 void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0, int g,
                 hipStream_t st);

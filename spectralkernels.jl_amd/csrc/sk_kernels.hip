@@ -1585,6 +1585,8 @@ __global__ void k_module_warmup(int* p) {
   if (p && threadIdx.x == 123456) *p = 0;
 }
 void launch_module_warmup(hipStream_t st) { hipLaunchKernelGGL(k_module_warmup, dim3(1), dim3(64), 0, st, (int*)nullptr); }
+// sk_launch_floor: the same empty kernel on a full grid
+void launch_empty(unsigned grid, hipStream_t st) { hipLaunchKernelGGL(k_module_warmup, dim3(grid), dim3(256), 0, st, (int*)nullptr); }
 
 void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st) {
   hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, st, dc, db, slot);
@@ -1628,6 +1630,15 @@ static unsigned genspread_resident() {
     cached = (unsigned)(per_cu * cus);
   }
   return cached;
+}
+unsigned launch_genspread_grid(const DevConst& dc) {
+  const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
+  unsigned grid = 0;
+  SK_DISPATCH_W(dc.w, {
+    const unsigned res = genspread_resident<W>();
+    grid = tiles + 1 < res ? tiles + 1 : res;
+  });
+  return grid;
 }
 void launch_genspread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int mode, int t, long long n, double k0,
                       double ks0, hipStream_t st) {

@@ -76,33 +76,62 @@ def test_c5_high_accuracy_1e5(sk, oracle):
     assert ks[0] == k0 and np.isnan(errs[0])
 
 
-def test_device_pointer_entry_with_torch(sk):
-    torch = pytest.importorskip("torch")
-    if not torch.cuda.is_available():
-        pytest.skip("torch sees no GPU")
+def test_device_pointer_entry(sk):
+    # HBM-resident arrays allocated through the library's own ABI: no torch / second HIP runtime in the process
     n = 200000
     rs = 10.0 ** np.linspace(-6, 0, n)
     cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5))
     host_ks, host_errs = sk.kernel_values(cfg, rs, k0=np.pi / 2)
-    d_rs = torch.from_numpy(rs).cuda()
-    d_ks = torch.empty_like(d_rs)
-    d_errs = torch.empty_like(d_rs)
-    st = torch.cuda.current_stream().cuda_stream
-    sk.kernel_values_device(cfg, d_rs.data_ptr(), n, np.pi / 2, d_ks.data_ptr(), d_errs.data_ptr(), stream_ptr=st)
-    assert np.array_equal(d_ks.cpu().numpy(), host_ks) and np.array_equal(d_errs.cpu().numpy(), host_errs)
+    d_rs = sk.DeviceArray.from_host(rs)
+    d_ks, d_errs = sk.DeviceArray(n), sk.DeviceArray(n)
+    sk.kernel_values_device(cfg, d_rs.ptr, n, np.pi / 2, d_ks.ptr, d_errs.ptr)
+    assert np.array_equal(d_ks.to_host(), host_ks) and np.array_equal(d_errs.to_host(), host_errs)
     # unsorted device input
-    perm = torch.randperm(n, device="cuda")
-    sk.kernel_values_device(cfg, d_rs[perm].contiguous().data_ptr(), n, np.pi / 2, d_ks.data_ptr(), d_errs.data_ptr(),
-                            stream_ptr=st)
-    assert np.array_equal(d_ks.cpu().numpy(), host_ks[perm.cpu().numpy()])
+    perm = np.random.default_rng(3).permutation(n)
+    d_p = sk.DeviceArray.from_host(rs[perm])
+    sk.kernel_values_device(cfg, d_p.ptr, n, np.pi / 2, d_ks.ptr, d_errs.ptr)
+    assert np.array_equal(d_ks.to_host(), host_ks[perm])
+
+
+def test_host_entry_pinned_and_pageable_agree(sk):
+    # arrays in pinned memory (sk_host_alloc) skip the staging pass; same results, bit for bit; unsorted input with
+    # duplicates goes through the device sort / dedup either way
+    n = 300000
+    rs = 10.0 ** np.linspace(-6, 0, n)
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5))
+    k0 = np.pi / 2
+    ks, errs = sk.kernel_values(cfg, rs, k0=k0)
+    px, pk, pe = sk.pinned_empty(n), sk.pinned_empty(n), sk.pinned_empty(n)
+    px[:] = rs
+    sk.kernel_values_into(cfg, px, k0, pk, pe)
+    assert np.array_equal(pk, ks) and np.array_equal(pe, errs)
+    rng = np.random.default_rng(5)
+    xs = np.r_[rs, rs[: n // 7]]
+    rng.shuffle(xs)
+    k2, e2 = sk.kernel_values(cfg, xs, k0=k0)
+    assert cfg.last_stats()["n_unique"] == n
+    truth = k0 * (1 + 2 * np.pi * xs) * np.exp(-2 * np.pi * xs)
+    assert np.abs(k2 - truth).max() / k0 <= 1e-7
+    order = np.argsort(xs, kind="stable")
+    assert np.array_equal(np.unique(xs), rs) and np.array_equal(k2[order][:: 1][np.r_[True, np.diff(xs[order]) > 0]], ks)
+    px2 = sk.pinned_empty(xs.size)
+    px2[:] = xs
+    pk2, pe2 = sk.pinned_empty(xs.size), sk.pinned_empty(xs.size)
+    sk.kernel_values_into(cfg, px2, k0, pk2, pe2)
+    assert np.array_equal(pk2, k2)
+    tm = sk.host_timing(cfg)
+    assert tm["total_ms"] > 0 and tm["total_ms"] >= tm["march_ms"]
+    with pytest.raises(sk.SpectralKernelsError) as ex:  # invalid lags are found while staging
+        sk.kernel_values(cfg, np.r_[rs[:40000], -1.0], k0=k0)
+    assert ex.value.code == 1
 
 
 def test_c4_dim2_pairwise_1e6(sk, oracle):
     # BASELINE config 4: isotropic dim-2 kernel (scripts/simple_2d.jl SDF) at the 10^6 pairwise lags of two
     # 10^3-point sets, lags formed on the device (src/model.jl:64-65), through the fast Hankel transform
     m = 1000
-    rng = np.random.default_rng(123)
-    X, Y = rng.uniform(0.0, 1.0, (m, 2)), rng.uniform(0.0, 1.0, (m, 2))
+    import bench  # the documented splitmix64 stream of SURVEY 8(d): the same C4 inputs as `bench.py --workload C4`
+    X, Y = bench.c4_points(m)
     pts = np.concatenate([X, Y])
     ii, jj = np.meshgrid(np.arange(m), m + np.arange(m), indexing="ij")
     pairs = np.stack([ii.ravel(), jj.ravel()], axis=1)

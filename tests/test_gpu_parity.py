@@ -392,13 +392,12 @@ def test_pairwise_lags_2d_points_isotropic_kernel(sk, oracle):
 def test_config_lifecycle_and_interleaving(sk, oracle):
     # many configs created / destroyed (grow-only workspaces, rocFFT plans, pinned status blocks are per config) and
     # two live configs used alternately: results must not depend on what else ran on the device
-    import torch
     rs = np.linspace(0.0, 3.0, 700)
     a = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5), quadspec=(256, 16))
     b = sk.AdaptiveKernelConfig(sk.SDF.exponential(1.0), quadspec=(128, 8), tol=1e-6)
     ka0, _ = sk.kernel_values(a, rs)
     kb0, _ = sk.kernel_values(b, rs)
-    free0 = torch.cuda.mem_get_info()[0]
+    free0 = sk.device_mem_info()[0]
     for i in range(40):
         c = sk.AdaptiveKernelConfig(sk.SDF.matern(1 + 0.01 * i, 1, 1.5), quadspec=(256, 16))
         kc, _ = sk.kernel_values(c, rs[: 50 + 10 * i])
@@ -409,8 +408,8 @@ def test_config_lifecycle_and_interleaving(sk, oracle):
         del c
     import gc
     gc.collect()
-    torch.cuda.synchronize()
-    assert free0 - torch.cuda.mem_get_info()[0] < 64 * 2 ** 20  # destroyed configs gave their memory back
+    sk.synchronize()
+    assert free0 - sk.device_mem_info()[0] < 64 * 2 ** 20  # destroyed configs gave their memory back
     assert np.abs(ka0 - oracle.matern_cov(rs, (1, 1, 1.5))).max() / ka0[0] <= 1e-7
 
 
