@@ -50,3 +50,14 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+
+
+def build_stamps(verbose=False):
+    """Diagnostic build with in-kernel s_memtime stamps (tools/diag/stamps*.py): tools/diag/libsk_stamps.so."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(os.path.dirname(HERE), "tools", "diag", "libsk_stamps.so")
+    cmd = [hipcc] + FLAGS + ["-DSK_STAMPS", "-shared", "-o", out] + [os.path.join(CSRC, f) for f in SOURCES] + ["-lrocfft"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out

@@ -256,7 +256,11 @@ static int wait_status(sk_config* cfg, unsigned int seq, hipStream_t st) {
 
 // core march on sorted unique lags already on the device (src/adaptive.jl:110-202)
 static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0, double ks0, double* d_ks, double* d_errs,
-                    double* d_scratch6n /* 10 n for logw */, hipStream_t st, bool check_flags) {
+                    double* d_scratch6n /* 10 n for logw */, hipStream_t st, bool check_flags,
+                    hipEvent_t lags_ready = nullptr) {
+  // lags_ready: the bulk of the lags is still being uploaded on another stream (only xs[0] and xs[n-1] are in
+  // place): the first step's node generation, spreading and FFT need no more than the largest lag
+  // (src/adaptive.jl:152) and run beside the upload; everything that reads all lags waits for the event
   DevBuffers& db = cfg->db;
   db.xs = d_uxs;
   db.ks = d_ks;
@@ -277,7 +281,11 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   // the host needs state_t before each step: callback SDFs (node values), Hankel (level split), logw (the first
   // panel takes two passes and a boundary term, src/quadrature.jl:186-228)
   const bool host_step = cb || hankel || logw;
-  db.check_input = (check_flags && !host_step) ? 1 : 0;
+  if (lags_ready && (host_step || cfg->dc.dim != 1 || g_no_fuse)) {
+    HIPCHK(hipStreamWaitEvent(st, lags_ready, 0));
+    lags_ready = nullptr;
+  }
+  db.check_input = (check_flags && !host_step && !lags_ready) ? 1 : 0;
   if (check_flags && host_step) launch_check_sorted(d_uxs, n, db.flags, st);  // k_gen never runs in INIT mode here
   sk_stats& stt = cfg->stats;
   const DevState* hs = &cfg->h_status->state;
@@ -331,6 +339,11 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         EvScope e(cfg, st, SK_K_FFT);
         int rc = run_fft(cfg, st);
         if (rc) return rc;
+      }
+      if (lags_ready) {  // first evaluation: from here on every lag is read
+        HIPCHK(hipStreamWaitEvent(st, lags_ready, 0));
+        lags_ready = nullptr;
+        if (check_flags) launch_check_sorted(d_uxs, n, db.flags, st);
       }
       { EvScope e(cfg, st, SK_K_INTERP); launch_interp(cfg->dc, cfg->d_ec, db, t & 1, n, raw, st); }
     } else if (hankel) {
@@ -465,6 +478,9 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     std::vector<unsigned long long> h(8 * 8192);
     (void)hipMemcpy(h.data(), db.stamps, h.size() * 8, hipMemcpyDeviceToHost);
     if (FILE* fp = fopen(f, "wb")) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); }
+    std::vector<unsigned long long> h2(16 * 4096);
+    (void)hipMemcpy(h2.data(), db.stamps2, h2.size() * 8, hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen((std::string(f) + ".interp").c_str(), "wb")) { fwrite(h2.data(), 8, h2.size(), fp); fclose(fp); }
   }
 #endif
   if (hs->done < 0) return fail(-hs->done, status_message(-hs->done));
@@ -472,7 +488,8 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
 }
 
 static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t n, double k0, double ks0, double* d_vals,
-                                     double* d_errs, hipStream_t st, int order = SK_ORDER_UNKNOWN) {
+                                     double* d_errs, hipStream_t st, int order = SK_ORDER_UNKNOWN,
+                                     hipEvent_t lags_ready = nullptr) {
   std::memset(&cfg->stats, 0, sizeof(cfg->stats));
   cfg->trace_len = 0;
   cfg->trace_valid = false;
@@ -490,7 +507,9 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   cfg->stats.n_unique = (int64_t)n;
   int unsorted = 1, invalid = 0;
   if (order != SK_ORDER_UNSORTED) {
-    rc = run_core(cfg, d_xs, (long long)n, k0, ks0, d_vals, d_errs, (double*)cfg->ws, st, order == SK_ORDER_UNKNOWN);
+    rc = run_core(cfg, d_xs, (long long)n, k0, ks0, d_vals, d_errs, (double*)cfg->ws, st, order == SK_ORDER_UNKNOWN,
+                  lags_ready);
+    lags_ready = nullptr;  // waited for in the stream
     if (order == SK_ORDER_SORTED) return rc;
     unsorted = cfg->h_status->flags[0];
     invalid = cfg->h_status->flags[1] & 1;
@@ -509,6 +528,7 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   if (invalid) return fail(SK_EINVAL, "lags must be non-negative and finite");
   if (!unsorted) return rc;
   // src/adaptive.jl:99-120: unique + sort, then gather back
+  if (lags_ready) HIPCHK(hipStreamWaitEvent(st, lags_ready, 0));
   std::memset(&cfg->stats, 0, sizeof(cfg->stats));
   const size_t tb = sort_unique_temp_bytes((long long)n);
   rc = ensure_ws(cfg, (4 + nscr) * a8 + tb + 256);
@@ -721,6 +741,8 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   (void)hipMemset(db.flags, 0, 2 * sizeof(int));
 #ifdef SK_STAMPS
   DA(8 * 8192, db.stamps);
+  DA(16 * 4096, db.stamps2);
+  (void)hipMemset(db.stamps2, 0, 16 * 4096 * 8);
 #endif
 #undef DA
   if (hipHostMalloc((void**)&cfg->h_status, sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
@@ -731,7 +753,8 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     return fail(SK_EHIP, "hipHostMalloc failed");
   }
   std::memset(cfg->h_status, 0, sizeof(HostStatus));
-  if (hipStreamCreate(&cfg->own_stream) != hipSuccess) {
+  if (hipStreamCreate(&cfg->own_stream) != hipSuccess || hipStreamCreate(&cfg->copy_stream) != hipSuccess ||
+      hipEventCreateWithFlags(&cfg->up_event, hipEventDisableTiming) != hipSuccess) {
     sk_config_destroy(cfg);
     return fail(SK_EHIP, "hipStreamCreate failed");
   }
@@ -847,6 +870,8 @@ void sk_config_destroy(sk_config* cfg) {
   for (double* q : cfg->h_fvpin)
     if (q) hipHostFree(q);
   if (cfg->own_stream) hipStreamDestroy(cfg->own_stream);
+  if (cfg->copy_stream) hipStreamDestroy(cfg->copy_stream);
+  if (cfg->up_event) hipEventDestroy(cfg->up_event);
   for (hipEvent_t e : cfg->ev_pool) hipEventDestroy(e);
   delete cfg;
 }
@@ -878,14 +903,15 @@ int sk_compute_k0(sk_config* cfg, double* k0) {
 }
 
 static int kernel_values_device_order(sk_config* cfg, const double* d_xs, size_t n, double k0, int param_derivative,
-                                      double* d_vals, double* d_errs, hipStream_t st, int order) {
+                                      double* d_vals, double* d_errs, hipStream_t st, int order,
+                                      hipEvent_t lags_ready = nullptr) {
   double ks0 = k0;  // src/adaptive.jl:134-145
   if (cfg->args.derivative) ks0 = 0.0;
   else if (param_derivative) {
     int rc = sk_compute_k0(cfg, &ks0);
     if (rc) return rc;
   }
-  return kernel_values_device_impl(cfg, d_xs, n, k0, ks0, d_vals, d_errs, st, order);
+  return kernel_values_device_impl(cfg, d_xs, n, k0, ks0, d_vals, d_errs, st, order, lags_ready);
 }
 
 int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double k0, int param_derivative, double* d_vals,
@@ -925,11 +951,28 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
   if (rc) return rc;
   double* d = cfg->d_io;
   hipStream_t st = cfg->own_stream;
+  // The bulk upload runs on the copy stream beside the first step's spreading and FFT, which only need the
+  // largest lag (and whether the smallest is zero): those two go ahead on the compute stream.
   int order = SK_ORDER_UNKNOWN;
-  rc = h2d_doubles(cfg, d, xs, n, st, &order);
-  if (rc) return rc;
+  hipEvent_t ready = nullptr;
+  if (n >= 65536) {
+    cfg->h_scal[1] = xs[0];
+    cfg->h_scal[2] = xs[n - 1];
+    HIPCHK(hipMemcpyAsync(d, &cfg->h_scal[1], sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d + n - 1, &cfg->h_scal[2], sizeof(double), hipMemcpyHostToDevice, st));
+    rc = h2d_doubles(cfg, d, xs, n, cfg->copy_stream, &order);
+    if (!rc && hipEventRecord(cfg->up_event, cfg->copy_stream) != hipSuccess) rc = fail(SK_EHIP, "hipEventRecord failed");
+    ready = cfg->up_event;
+  } else {
+    rc = h2d_doubles(cfg, d, xs, n, st, &order);
+  }
+  if (rc) {
+    (void)hipStreamSynchronize(cfg->copy_stream);
+    return rc;
+  }
   const double t_up = ms_since(t0);
-  rc = kernel_values_device_order(cfg, d, n, k0, param_derivative, d + n, d + 2 * n, st, order);
+  rc = kernel_values_device_order(cfg, d, n, k0, param_derivative, d + n, d + 2 * n, st, order, ready);
+  if (rc && ready) (void)hipStreamSynchronize(cfg->copy_stream);
   const double t_march = ms_since(t0);
   if (!rc) rc = d2h_doubles2(cfg, vals_out, errs_out, d + n, n, st);
   const double t_all = ms_since(t0);

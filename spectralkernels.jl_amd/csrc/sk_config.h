@@ -61,6 +61,7 @@ struct sk_config {
   double* h_out = nullptr;
   size_t hout_bytes = 0;
   std::vector<std::atomic<int>> chunk_done;  // threads done with chunk c of the staged upload
+  std::vector<size_t> chunk_edge;            // chunk boundaries of the transfer in progress
   std::vector<hipEvent_t> cp_events;         // one per download chunk
   double host_timing[4] = {0, 0, 0, 0};      // last sk_kernel_values call: upload, march, download, total (ms)
   // grow-only device scratch of the multi / pairs / dense entries (points, index pairs, per-config results)
@@ -78,6 +79,8 @@ struct sk_config {
   double* h_scal = nullptr;        // pinned scalars handed to small asynchronous uploads
   double* h_fvpin[2] = {nullptr, nullptr};  // callback SDFs: pinned copies of the integrand values of a pass
   hipStream_t own_stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // bulk upload of the host-array entry, beside the first step (up_event)
+  hipEvent_t up_event = nullptr;
   // last call
   sk_stats stats;
   std::vector<TraceRec> trace;

@@ -166,6 +166,7 @@ struct DevBuffers {
   // logw first-panel passes (src/quadrature.jl:186-228): raw panel sums A (rules 1, 2) then B (rules 1, 2), n each
   double* lw_raw;
   unsigned long long* stamps;  // diagnostic builds only (SK_STAMPS): 8 words per k_spread workgroup
+  unsigned long long* stamps2; // diagnostic builds only: 16 words per k_interp2 workgroup
 };
 
 // launchers (sk_kernels.hip)

@@ -3,7 +3,8 @@
 //
 // A pageable hipMemcpy of the 24 MB of BASELINE config 2 (8 MB of lags in, 16 MB of values and error estimates
 // out) costs ~3.5 ms on this stack (single-threaded staging inside the runtime), against 0.12 ms for the march
-// itself.  Here every DMA runs from / to pinned staging buffers owned by the config, in 1 MB chunks:
+// itself.  Here every DMA runs from / to pinned staging buffers owned by the config, in chunks:
+//   (a few chunks of growing / shrinking size, see make_chunks)
 //   in:  T host threads copy chunk c into the pinned buffer (each its own slice) while the DMA engine moves chunk
 //        c-1; the same pass checks that the lags are valid and strictly increasing (src/adaptive.jl:99,113), so the
 //        march needs no speculative start on the device;
@@ -13,13 +14,14 @@
 // No pageable pointer is ever handed to an asynchronous HIP copy.
 #include <omp.h>
 #include <immintrin.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include "sk_config.h"
 
 namespace sk {
 
-static const size_t kChunk = (size_t)1 << 17;       // doubles per DMA chunk (1 MB)
+static const size_t kChunk = (size_t)1 << 17;       // smallest DMA chunk, doubles (1 MB)
 static const size_t kSerialMax = (size_t)1 << 14;   // below this many doubles one thread does the staging
 
 static int copy_threads() {
@@ -51,6 +53,24 @@ static int ensure_stage(double** buf, size_t* have, size_t doubles) {
   HIPCHK(hipHostMalloc((void**)buf, bytes, hipHostMallocDefault));
   *have = bytes;
   return SK_OK;
+}
+
+// Chunk boundaries of [0, total): sizes halve from total/2 down to kChunk (download: the last chunk, whose drain
+// is exposed, is small; every DMA costs ~9 us of fixed overhead on this stack -- 16 MB in 1 MB chunks took 450 us
+// against 305 us in one piece -- so there are only log2 many); `growing` reverses the order (upload: the first
+// chunk, whose staging copy is exposed, is small).
+static void make_chunks(size_t total, bool growing, std::vector<size_t>& edge) {
+  std::vector<size_t> len;
+  size_t rem = total;
+  while (rem > 2 * kChunk) {
+    size_t c = ((rem / 2 + kChunk - 1) / kChunk) * kChunk;
+    len.push_back(c);
+    rem -= c;
+  }
+  if (rem) len.push_back(rem);
+  if (growing) std::reverse(len.begin(), len.end());
+  edge.assign(1, 0);
+  for (size_t c : len) edge.push_back(edge.back() + c);
 }
 
 // slice q of nt of [lo, hi)
@@ -90,8 +110,10 @@ int h2d_doubles(sk_config* cfg, double* d_dst, const double* src, size_t cnt, hi
     HIPCHK(hipMemcpyAsync(d_dst, stage, cnt * sizeof(double), hipMemcpyHostToDevice, st));
     return SK_OK;
   }
-  const size_t nch = (cnt + kChunk - 1) / kChunk;
-  if (cfg->chunk_done.size() < nch) cfg->chunk_done = std::vector<std::atomic<int>>(nch + nch / 2 + 8);
+  std::vector<size_t>& edge = cfg->chunk_edge;
+  make_chunks(cnt, true, edge);
+  const size_t nch = edge.size() - 1;
+  if (cfg->chunk_done.size() < nch) cfg->chunk_done = std::vector<std::atomic<int>>(nch + 8);
   for (size_t c = 0; c < nch; ++c) cfg->chunk_done[c].store(0, std::memory_order_relaxed);
   std::atomic<int> flags{0}, err{0};
   const bool want_order = order != nullptr;
@@ -100,7 +122,7 @@ int h2d_doubles(sk_config* cfg, double* d_dst, const double* src, size_t cnt, hi
     const int nt = omp_get_num_threads(), q = omp_get_thread_num();
     int f = 0;
     for (size_t c = 0; c < nch; ++c) {
-      const size_t lo = c * kChunk, hi = lo + kChunk < cnt ? lo + kChunk : cnt;
+      const size_t lo = edge[c], hi = edge[c + 1];
       size_t a, b;
       slice_of(lo, hi, q, nt, a, b);
       if (b > a) {
@@ -154,14 +176,16 @@ int d2h_doubles2(sk_config* cfg, double* dst_a, double* dst_b, const double* d_s
     drain(0, total);
     return SK_OK;
   }
-  const size_t nch = (total + kChunk - 1) / kChunk;
+  std::vector<size_t>& edge = cfg->chunk_edge;
+  make_chunks(total, false, edge);
+  const size_t nch = edge.size() - 1;
   while (cfg->cp_events.size() < nch) {
     hipEvent_t e;
     HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     cfg->cp_events.push_back(e);
   }
   for (size_t c = 0; c < nch; ++c) {
-    const size_t lo = c * kChunk, hi = lo + kChunk < total ? lo + kChunk : total;
+    const size_t lo = edge[c], hi = edge[c + 1];
     HIPCHK(hipMemcpyAsync(stage + lo, d_src + lo, (hi - lo) * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(cfg->cp_events[c], st));
   }
@@ -179,7 +203,7 @@ int d2h_doubles2(sk_config* cfg, double* dst_a, double* dst_b, const double* d_s
         while ((r = ready.load(std::memory_order_acquire)) >= 0 && r < (long long)c + 1) _mm_pause();
       }
       if (ready.load(std::memory_order_acquire) < 0) break;
-      const size_t lo = c * kChunk, hi = lo + kChunk < total ? lo + kChunk : total;
+      const size_t lo = edge[c], hi = edge[c + 1];
       size_t a, b;
       slice_of(lo, hi, q, nt, a, b);
       if (b > a) drain(a, b);

@@ -13,6 +13,7 @@
 // evaluated redundantly by every workgroup of the next k_gen (no extra launch); k_advance runs it
 // only at round boundaries, where the host reads the state through a pinned status block.
 // All state lives in HBM (DevState ping-pong), so steps run back to back with no host hop.
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <hip/hip_runtime.h>
@@ -889,13 +890,25 @@ __device__ __forceinline__ int tap_base(double r, double r_hi, double inv_rc, do
   return (int)fmin(fmax(k0d, -(double)(n2 / 2)), (double)(n2 / 2 - W)) + n2 / 2;
 }
 
+// A read-only table seen through the constant address space: its uniform-address loads are scalar loads whatever
+// else the kernel does.  Through a plain pointer the compiler only emits scalar loads while it can prove that
+// nothing ahead of them may write memory -- a store, an atomic or even an opaque intrinsic ahead of the table
+// loads silently turns them into uniform-address vector loads (+17 us on k_interp when it happened).
+typedef const double __attribute__((address_space(4))) * const_table;
+__device__ __forceinline__ const_table as_const_table(const double* p) { return (const_table)(unsigned long long)p; }
+// one value of memory that no other kernel writes while this one runs (state of the step, lags), read the same way
+template <class T>
+__device__ __forceinline__ T const_load(const T* p) {
+  return *(const T __attribute__((address_space(4)))*)(unsigned long long)p;
+}
+
 // The W ES-kernel weights of a lag with kernel offset y, tables read by scalar loads (k_interp & co).
 // The even/odd polynomials are summed against precomputed powers of y^2 with the coefficient as the
 // *multiplicand*: v_fmac_f64 acc, s[coef], v[power].  Horner (E = E*y2 + coef) puts the SGPR coefficient in
 // the addend, and the compiler then copies every coefficient into a VGPR pair first (2 v_mov_b32 per step:
 // 200 of k_interp's 590 VALU instructions per wave, found with SQ_INSTS_VALU / the ISA histogram).
-template <int W>
-__device__ __forceinline__ void es_weights(const double* poly, double y, double (&wt)[W]) {
+template <int W, class TablePtr>
+__device__ __forceinline__ void es_weights(TablePtr poly, double y, double (&wt)[W]) {
   constexpr int NCO = W / 2 + 1;
   const double y2 = y * y;
   double pw[NCO];  // pw[i] = y2^i
@@ -905,8 +918,8 @@ __device__ __forceinline__ void es_weights(const double* poly, double y, double 
   for (int i = 2; i < NCO; ++i) pw[i] = pw[i - 1] * y2;
 #pragma unroll
   for (int q = 0; q < W / 2; ++q) {
-    const double* pe = poly + q * 2 * NCO;  // highest power first
-    const double* po = pe + NCO;
+    const auto pe = poly + q * 2 * NCO;  // highest power first
+    const auto po = pe + NCO;
     double E = pe[0] * pw[NCO - 1], O = po[0] * pw[NCO - 1];
 #pragma unroll
     for (int i = 1; i < NCO - 1; ++i) {  // smallest terms first
@@ -1157,6 +1170,256 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
     if (h) atomicMax(&rd.hi[a], h);
     if (f) atomicOr(&rd.nan, f);
   }
+}
+
+// k_interp2: the same evaluation as k_interp<W, SK_RAW_NONE> (dim 1, value or derivative), re-scheduled around its
+// memory round trips -- k_interp spends more than half of its wave time in s_waitcnt on a chain
+//   kernel arguments -> state -> window bounds (xs[first], xs[last]) -> FFT-output window -> LDS -> arithmetic,
+// with the lag's own loads issued only after the state has arrived.  Here
+//   * everything that depends on the kernel arguments only is issued first and together: the lag r (clamped
+//     index), the block's first / second / last lag for the window bounds (scalar), the state (scalar);
+//   * the window is loaded to registers, then the kernel weights (the ES table's scalar loads and ~100 FMAs), the
+//     post-phase and 1/phi_hat are computed while it is in flight, and only then is it written to LDS;
+//   * scalar table loads and LDS tap reads share the lgkm counter (a wait for one drains the other): the weights
+//     are complete before the first tap is read, so the two never overlap;
+//   * every lane computes (inactive lanes are masked at the stores and in the reductions): no divergence.
+// Windows are capped at 256 samples per rule (one per thread); sparser lag sets gather their taps from memory.
+// Measured at 10^6 lags (rocprofv3): 23.0 us against 24.1 us for k_interp.  In-kernel stamps (tools/diag/
+// stamps_interp.py) show why no re-scheduling moves it much: 7 workgroups per CU are alive, each for ~6 us = 7 x its
+// own VALU time -- the steady state is VALU-issue bound (about 235 FP64 and 200 other vector instructions per wave) at
+// ~70 % utilisation, then the last of 2.2 rounds of workgroups drains at falling occupancy for a quarter of the launch.
+// Tried on top of this and measured slower: 5 or 8 waves per SIMD (23.9 / 24.5 us; 8 needs spills), one wave per
+// workgroup with per-wave windows and per-wave global atomics (132 us: four times the atomics on the same few cache
+// lines serialise in L2), the same with the reduction through LDS by the last wave to arrive (24.9 us).
+constexpr int kWin2 = 256;
+template <int W, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_interp2(DevConst dc, const EsConst* ec, DevBuffers db, int slot, long long n) {
+  __shared__ double smax[4];
+  __shared__ unsigned int shi[4];
+  __shared__ int sflag[4][2];
+  __shared__ double2 s_win[2 * kWin2];
+  const long long blk0 = (long long)blockIdx.x * 256;  // first lag of this workgroup (< n by the grid size)
+  const long long i = blk0 + threadIdx.x;
+#ifdef SK_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- loads that need nothing but the kernel arguments
+  const long long ic = i < n ? i : n - 1;
+  const double r = db.xs[ic];
+  const long long i_last = blk0 + 255 < n ? blk0 + 255 : n - 1;
+  const double r_first = const_load(&db.xs[blk0]), r_second = const_load(&db.xs[blk0 + 1 < n ? blk0 + 1 : blk0]),
+               r_lastn = const_load(&db.xs[i_last]);
+  const DevState& s = db.state[slot];
+  const int done = const_load(&s.done);
+  const long long sn = const_load(&s.n);
+  PanelParams pp;
+  pp.Cx = const_load(&s.pp.Cx);
+  pp.r_hi = const_load(&s.pp.r_hi);
+  pp.inv_rc = const_load(&s.pp.inv_rc);
+  pp.tau = const_load(&s.pp.tau);
+  pp.theta_scale = const_load(&s.pp.theta_scale);
+  pp.jacobi = const_load(&s.pp.jacobi);
+  TailScalars tail;
+  tail.t1 = const_load(&s.tail.t1);
+  tail.t2num = const_load(&s.tail.t2num);
+  tail.crit = const_load(&s.tail.crit);
+  const int conf = const_load(&s.conf), has_acc = const_load(&s.has_acc), pc = const_load(&s.pc),
+            p_valid = const_load(&s.p_valid), stack_len = const_load(&s.stack_len);
+  const double T2 = dc.tol * const_load(&s.k0abs) * 0.5;
+  const long long ix1 = const_load(&s.ix1), hi = const_load(&s.hi);
+  const unsigned bad = (unsigned)(done != 0) | (unsigned)(sn != n) | (unsigned)((unsigned long long)ix1 > 1ull) |
+                       (unsigned)(hi < 0) | (unsigned)(hi > n) | (unsigned)((unsigned)conf > 1u) | (unsigned)((unsigned)pc > 1u) |
+                       (unsigned)((unsigned)stack_len > (unsigned)kStackCap) | (unsigned)((unsigned)pp.jacobi > 1u) |
+                       (unsigned)((unsigned)has_acc > 1u) | (unsigned)((unsigned)p_valid > 1u) |
+                       (unsigned)((unsigned)tail.crit > 2u) | (unsigned)(T2 != T2) | (unsigned)(pp.r_hi != pp.r_hi) |
+                       (unsigned)(pp.tau != pp.tau) | (unsigned)(pp.Cx != pp.Cx) | (unsigned)(pp.theta_scale != pp.theta_scale) |
+                       (unsigned)(pp.inv_rc != pp.inv_rc);
+  if (bad | (unsigned)(blk0 >= hi)) {
+    // Never taken (slot is 0 or 1): a use of the early loads on this side of the branch keeps them ahead of it --
+    // the compiler would otherwise sink them below the branch, behind the state's round trip.  (No store here: a
+    // store anywhere ahead of the table loads turns those from scalar into uniform vector loads.)
+    if (slot == 0x7fffffff && r + r_first + r_second + r_lastn == 0.5) __builtin_amdgcn_s_sleep(1);
+    return;
+  }
+  const double* const cK = conf ? db.accK[1] : db.accK[0];
+  const double* const cE = conf ? db.accE[1] : db.accE[0];
+  double* const oK = conf ? db.accK[0] : db.accK[1];
+  double* const oE = conf ? db.accE[0] : db.accE[1];
+  const double* const pIn = pc ? db.P[1] : db.P[0];
+  double* const pOut = pc ? db.P[0] : db.P[1];
+  const bool act = (i >= ix1 && i < hi);
+  // ---- the lag's own tap position first: it waits for r (in flight since before the state's round trip) while
+  // nothing else is outstanding, so that no later wait on r also has to drain the loads issued below
+  const int n2i = (int)dc.n2, n1i = n2i >> 1;
+#ifdef SK_STAMPS
+  const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): r
+#ifdef SK_STAMPS
+  const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
+  double v, y;
+  const int base = tap_base<W>(r, pp.r_hi, pp.inv_rc, pp.tau, n2i, v, y);
+  // ---- window of the FFT output that holds the taps of this workgroup's active lags (sorted)
+  double r_a = blk0 < ix1 ? r_second : r_first;  // ix1 is 0 or 1: only the first workgroup can start below it
+  double r_b = r_lastn;
+  if (blk0 + 256 > hi) r_b = const_load(&db.xs[hi - 1]);  // the last active workgroup only (a dependent scalar load)
+  int wbase, wsize;
+  {
+    double vv, yy;
+    wbase = tap_base<W>(r_a, pp.r_hi, pp.inv_rc, pp.tau, n2i, vv, yy);
+    wsize = tap_base<W>(r_b, pp.r_hi, pp.inv_rc, pp.tau, n2i, vv, yy) - wbase + W;
+  }
+  const bool use_win = (wsize >= W && wsize <= kWin2);  // workgroup-uniform
+  double2 g1 = make_double2(0.0, 0.0), g2 = g1;
+  if (use_win && (int)threadIdx.x < wsize) {
+    // output sample m of rule R is element m >> 1 of transform 2R + (m & 1) (see k_spread)
+    const int m = wbase + (int)threadIdx.x;
+    const double2* src = db.fft_out + (size_t)(m & 1) * n1i + (m >> 1);
+    g1 = src[0];
+    g2 = src[2 * (size_t)n1i];
+  }
+  // ---- confirmed sums: they depend on the state only (which buffer); issued behind the window loads, consumed last
+  double ck = 0.0, ce = 0.0, pin = 0.0;
+  if (has_acc) {
+    ck = cK[ic];
+    ce = cE[ic];
+  }
+  if (p_valid) pin = pIn[ic];
+  // ---- arithmetic that needs the lag only, in stages that keep few scalars alive at a time (the ES table alone is
+  // 168 SGPRs' worth of coefficients; with the state still live the compiler spills SGPRs into VGPR lanes):
+  // (1) tap position, convergence bound, post-phase and 1/phi_hat -- the last uses of the panel scalars;
+  const bool imag = dc.derivative != 0;  // real part for :cos, imaginary for :sin (src/quadrature.jl:128-133)
+  const int crit = tail.crit;
+  const double te = (crit == SK_CRIT_PANEL) ? 0.0 : trunc_est(tail, r, dc.dim);
+  // bit 0: the truncation half of the convergence predicate holds, bit 1: the panel half is waived (:tails),
+  // bit 2: this evaluation completes an outer panel (stack empty)
+  const int cflags = ((crit == SK_CRIT_PANEL || te < T2) ? 1 : 0) | (crit == SK_CRIT_TAILS ? 2 : 0) | (stack_len == 0 ? 4 : 0);
+  const double T2v = T2;
+  double pcoef, qcoef;
+  {
+    const double th = (pp.theta_scale * dc.inv_theta_max) * v;
+    double sarg = 2.0 * th * th - 1.0;
+    sarg = sarg > 1.0 ? 1.0 : sarg;
+    const const_table s_cheb = as_const_table(ec->cheb);
+    double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+    for (int kq = 15; kq >= 1; --kq) {  // ncheb == 16 (sk_tables.cpp)
+      const double b0 = fma(2.0 * sarg, b1, s_cheb[kq] - b2);
+      b2 = b1;
+      b1 = b0;
+    }
+    const double invhat = fma(sarg, b1, s_cheb[0] - b2);
+    const double2 ph = cis_turns_prod(pp.Cx, r);
+    pcoef = (imag ? ph.y : ph.x) * invhat * dc.c;   // the scale c (src/quadrature.jl:250-255, dim 1) folded in
+    qcoef = (imag ? ph.x : -ph.y) * invhat * dc.c;
+  }
+#ifdef SK_STAMPS
+  const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+#endif
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- window to LDS
+  if (use_win && (int)threadIdx.x < wsize) {
+    s_win[threadIdx.x] = g1;
+    s_win[kWin2 + threadIdx.x] = g2;
+  }
+  __syncthreads();
+#ifdef SK_STAMPS
+  const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+#endif
+  // (2) the W kernel weights (wave-uniform table addresses: scalar loads), complete before the first tap is read
+  double wt[W];
+  es_weights<W>(as_const_table(ec->poly), y, wt);
+  __builtin_amdgcn_sched_barrier(0);
+#ifdef SK_STAMPS
+  const unsigned long long st5 = __builtin_amdgcn_s_memtime();
+#endif
+  double h1r = 0, h1i = 0, h2r = 0, h2i = 0;
+  if (use_win) {
+    int off = base - wbase;
+    off = off < 0 ? 0 : (off > wsize - W ? wsize - W : off);  // clamps for inactive lanes / unsorted (speculative) input only
+    const double2* t1 = s_win + off;
+    const double2* t2 = s_win + kWin2 + off;
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      const double2 a1 = t1[q], a2 = t2[q];
+      h1r = fma(a1.x, wt[q], h1r); h1i = fma(a1.y, wt[q], h1i);
+      h2r = fma(a2.x, wt[q], h2r); h2i = fma(a2.y, wt[q], h2i);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      const int m = base + q;
+      const double2* src = db.fft_out + (size_t)(m & 1) * n1i + (m >> 1);
+      const double2 a1 = src[0], a2 = src[2 * (size_t)n1i];
+      h1r = fma(a1.x, wt[q], h1r); h1i = fma(a1.y, wt[q], h1i);
+      h2r = fma(a2.x, wt[q], h2r); h2i = fma(a2.y, wt[q], h2i);
+    }
+  }
+  const double I1 = fma(h1i, qcoef, h1r * pcoef);
+  const double I2 = fma(h2i, qcoef, h2r * pcoef);
+#ifdef SK_STAMPS
+  asm volatile("" :: "v"(I1), "v"(I2));
+  const unsigned long long st6 = __builtin_amdgcn_s_memtime();
+#endif
+  double emax = 0.0;
+  int n1f = 0, n2f = 0;
+  unsigned int unconv = 0u;
+  if (act) {
+    const double e = fabs(I2 - I1);
+    emax = e;
+    n1f = isnan(I1);
+    n2f = isnan(I2);
+    const double Sk = ck + I2, Se = ce + e;
+    oK[i] = Sk;
+    oE[i] = Se;
+    const double pk = pin + I2;
+    if (cflags & 4) {
+      const bool conv = (cflags & 1) && ((cflags & 2) || fabs(pk) < T2v);
+      unconv = conv ? 0u : (unsigned int)(i + 1);
+      if (conv) {  // see k_interp: only a converged lag can retire with this evaluation
+        db.ks[i] = Sk;
+        db.errs[i] = Se + 2.0 * te;
+      }
+    } else {
+      pOut[i] = pk;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) emax = fmax(emax, __shfl_xor(emax, off, 64));
+  const unsigned long long um = __ballot(unconv != 0u);
+  const unsigned int wave_unconv = um ? (unsigned int)(blk0 + (threadIdx.x & ~63u) + (63 - __builtin_clzll(um)) + 1) : 0u;
+  const int a1f = __any(n1f), a2f = __any(n2f);
+  if ((threadIdx.x & 63) == 0) {
+    smax[threadIdx.x >> 6] = emax;
+    shi[threadIdx.x >> 6] = wave_unconv;
+    sflag[threadIdx.x >> 6][0] = a1f;
+    sflag[threadIdx.x >> 6][1] = a2f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double b = smax[0];
+    unsigned int h = shi[0];
+    int f = 0;
+    for (int w2 = 0; w2 < 4; ++w2) {
+      b = fmax(b, smax[w2]);
+      h = shi[w2] > h ? shi[w2] : h;
+      f |= (sflag[w2][0] ? 1 : 0) | (sflag[w2][1] ? 2 : 0);
+    }
+    Reductions& rd = db.red[slot];
+    const int a = blockIdx.x & 63;
+    if (b > 0.0) atomicMax(&rd.max_bits[a], (unsigned long long)__double_as_longlong(b));
+    if (h) atomicMax(&rd.hi[a], h);
+    if (f) atomicOr(&rd.nan, f);
+  }
+#ifdef SK_STAMPS
+  if (threadIdx.x == 0 && db.stamps2 && blockIdx.x < 4096) {
+    unsigned long long* o = db.stamps2 + (size_t)blockIdx.x * 16;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = st5; o[6] = st6;
+    o[7] = __builtin_amdgcn_s_memtime(); o[8] = sr0; o[9] = __builtin_amdgcn_s_memrealtime();
+    o[10] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+    o[11] = (unsigned long long)use_win;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ shared epilogue (dim >= 2, logw)
@@ -1670,14 +1933,18 @@ void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long
 void launch_lw_finish(const DevConst& dc, const DevBuffers& db, int slot, long long n, double B0, hipStream_t st) {
   hipLaunchKernelGGL(k_lw_finish, dim3(nblk(n, 256)), dim3(256), 0, st, dc, db, slot, n, B0);
 }
+// SK_INTERP=1 selects the first-generation k_interp for the plain evaluation (A/B timing)
+static const int g_interp_variant = getenv("SK_INTERP") ? atoi(getenv("SK_INTERP")) : 2;
 void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, int raw, hipStream_t st) {
   const unsigned g = nblk(n, 256);
   if (raw == SK_RAW_A) {
     SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp<W, SK_RAW_A>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
   } else if (raw == SK_RAW_B) {
     SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp<W, SK_RAW_B>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
-  } else {
+  } else if (g_interp_variant == 1) {
     SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp<W, SK_RAW_NONE>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
+  } else {
+    SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp2<W, 7>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
   }
 }
 
