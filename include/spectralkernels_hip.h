@@ -75,6 +75,9 @@ typedef struct {
   int nufft_width;         /* 0 = choose from tol; else spreading width w in [4,16] */
   int hankel_min_lags;     /* dim >= 2: use the fast Hankel transform for >= this many unique lags, the direct
                               Bessel-sum kernel below (0 = default 2048; -1 = always direct) */
+  int sdf_dparam;          /* catalogue SDFs: 0 = the SDF itself; j >= 1 = its derivative with respect to
+                              sdf_params[j-1] -- the integrands of kernel_sdf_derivatives (src/derivatives.jl:61-72),
+                              evaluated on the device.  Matern: phi, rho, nu; exponential, gaussian: a. */
 } sk_config_args;
 
 typedef struct sk_config sk_config; /* opaque */
@@ -148,6 +151,17 @@ int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double
  * cfgs: ncfg configs on the same device; k0s / param_derivative: one entry per config (as in sk_kernel_values
  * with has_k0 = 1); vals_out / errs_out: ncfg x n, row c = config c in input order. */
 int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, const double* k0s,
+                           const int* param_derivative, double* vals_out, double* errs_out);
+
+/* The same integrands in ONE joint panel march: shared nodes, spreading weights, tap positions,
+ * interpolation weights and post-phases; per integrand only the source strengths (one batched type-3 NUFFT with
+ * one transform per integrand, two for logw) and the running sums.  A (sub)panel is accepted when every integrand
+ * passes max|I2-I1| < tol |k0| (src/quadrature.jl:260), a lag retires when every integrand's convergence predicate
+ * holds (src/adaptive.jl:183-198): results within tol of the separate marches of sk_kernel_values_multi, whose
+ * schedules can only be shorter.  cfgs[0] must be the plain kernel (derivative = logw = 0); all configs: dim 1,
+ * catalogue SDFs (incl. sdf_dparam), equal quadspec / tol / alpha / criteria / tail; one k0 for all, as the
+ * reference passes it (src/derivatives.jl:57,71,81).  vals_out / errs_out: ncfg x n. */
+int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, double k0,
                            const int* param_derivative, double* vals_out, double* errs_out);
 
 /* One process, several GPUs (the reference's kernel_values is one call on one host Vector,

@@ -19,7 +19,7 @@ class ConfigArgs(C.Structure):
                 ("df", SDF_BATCH_FN), ("df_ctx", C.c_void_p), ("dim", C.c_int), ("alpha", C.c_double),
                 ("tol", C.c_double), ("derivative", C.c_int), ("logw", C.c_int), ("criteria", C.c_int),
                 ("has_tail", C.c_int), ("tail", C.c_double), ("m", C.c_int64), ("k", C.c_int64),
-                ("device", C.c_int), ("nufft_width", C.c_int), ("hankel_min_lags", C.c_int)]
+                ("device", C.c_int), ("nufft_width", C.c_int), ("hankel_min_lags", C.c_int), ("sdf_dparam", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -60,6 +60,7 @@ def load():
     L.sk_kernel_values.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp]
     L.sk_kernel_values_device.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_int, vp, vp, vp]
     L.sk_kernel_values_multi.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp]
+    L.sk_kernel_values_joint.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_double, vp, vp, vp]
     L.sk_kernel_values_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp]
     L.sk_kernel_values_pairs_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_double, C.c_int, vp, vp, vp]
     L.sk_dense_cov_matrix.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]

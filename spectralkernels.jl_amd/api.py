@@ -25,8 +25,32 @@ class SpectralKernelsError(RuntimeError):
 class SDF:
     """Spectral density: a device-catalogue entry or a host callable (evaluated in batches)."""
 
-    def __init__(self, kind, params=(), fn=None):
-        self.kind, self.params, self.fn = kind, tuple(float(p) for p in params), fn
+    def __init__(self, kind, params=(), fn=None, dparam=0):
+        self.kind, self.params, self.fn, self.dparam = kind, tuple(float(p) for p in params), fn, int(dparam)
+
+    def d(self, j):
+        """dS/d(parameter j) of a catalogue SDF (zero-based: matern phi, rho, nu; exponential / gaussian a), evaluated
+        on the device: the integrands of kernel_sdf_derivatives (src/derivatives.jl:61-72)."""
+        if self.kind == L.SDF_CALLBACK:
+            raise SpectralKernelsError(L.SK_EINVAL, "parameter derivatives of a callback SDF: pass the derivative as its own callback")
+        return SDF(self.kind, self.params, None, int(j) + 1)
+
+    def __call__(self, w):
+        """Host evaluation of a catalogue entry (tests, callbacks mirroring the device formulas)."""
+        w = np.asarray(w, dtype=np.float64)
+        p = self.params
+        if self.kind == L.SDF_MATERN:
+            x = p[1] ** 2 + w * w
+            e = -p[2] - p[3] / 2.0
+            S = p[0] * x ** e
+            return [S, S / p[0], S * e * 2.0 * p[1] / x, -S * np.log(x)][self.dparam]
+        if self.kind == L.SDF_EXPONENTIAL:
+            S = np.exp(-p[0] * np.abs(w))
+            return [S, -np.abs(w) * S][self.dparam]
+        if self.kind == L.SDF_GAUSSIAN:
+            S = np.exp(-(w * w) / p[0] ** 2)
+            return [S, S * 2.0 * w * w / p[0] ** 3][self.dparam]
+        return self.fn(w)
 
     @staticmethod
     def matern(phi, rho, nu, d=1):
@@ -98,6 +122,7 @@ def _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, t
     a.device = int(device)
     a.nufft_width = int(nufft_width)
     a.hankel_min_lags = int(hankel_min_lags)
+    a.sdf_dparam = int(getattr(f, "dparam", 0))
     return a, keep, f
 
 
@@ -228,6 +253,22 @@ def kernel_values_multi(configs, xs, k0s, param_derivative=False):
     handles = (C.c_void_p * nc)(*[c._h for c in configs])
     vals, errs = np.zeros((nc, n)), np.zeros((nc, n))
     _check(L.load().sk_kernel_values_multi(handles, nc, xs.ctypes.data_as(C.c_void_p), n, k0s.ctypes.data_as(C.c_void_p),
+                                           pds.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
+                                           errs.ctypes.data_as(C.c_void_p)))
+    return vals, errs
+
+
+def kernel_values_joint(configs, xs, k0, param_derivative=False):
+    """The integrands of `configs` on one lag set in ONE joint panel march (sk_kernel_values_joint): shared nodes,
+    spreading and interpolation weights, one batched NUFFT; a panel is accepted / a lag retired when every integrand
+    agrees.  configs[0] is the plain kernel; the others differ in the integrand only (SDF.d(j), derivative=True,
+    logw=True).  One k0 for all (src/derivatives.jl:57,71,81).  Returns (vals, errs) of shape (len(configs), len(xs))."""
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    nc, n = len(configs), xs.size
+    pds = np.ascontiguousarray(np.broadcast_to(np.asarray(param_derivative, dtype=bool), (nc,)).astype(np.int32))
+    handles = (C.c_void_p * nc)(*[c._h for c in configs])
+    vals, errs = np.zeros((nc, n)), np.zeros((nc, n))
+    _check(L.load().sk_kernel_values_joint(handles, nc, xs.ctypes.data_as(C.c_void_p), n, float(k0),
                                            pds.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
                                            errs.ctypes.data_as(C.c_void_p)))
     return vals, errs

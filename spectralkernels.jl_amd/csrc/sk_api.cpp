@@ -78,6 +78,11 @@ static int validate(const sk_config_args& a, int64_t& m, int64_t& k, int& warned
   if (p != 0.0 && p <= -1.0) return fail(SK_EINVAL, "p needs to be in (-1.0, Inf) to be integrable");
   if (a.sdf_kind == SK_SDF_CALLBACK && !a.f) return fail(SK_EINVAL, "sdf callback is null");
   if (a.sdf_kind < 0 || a.sdf_kind > SK_SDF_GAUSSIAN) return fail(SK_EINVAL, "unknown sdf_kind");
+  {
+    const int np = a.sdf_kind == SK_SDF_MATERN ? 3 : (a.sdf_kind == SK_SDF_CALLBACK ? 0 : 1);
+    if (a.sdf_dparam < 0 || a.sdf_dparam > np) return fail(SK_EINVAL, "sdf_dparam out of range for this sdf_kind");
+    if (a.sdf_dparam && a.logw) return fail(SK_EUNSUPPORTED, "logw=true with a parameter-derivative integrand");
+  }
   return SK_OK;
 }
 
@@ -253,6 +258,8 @@ static int wait_status(sk_config* cfg, unsigned int seq, hipStream_t st) {
   cfg->stats.n_syncs++;
   return SK_OK;
 }
+
+int joint_wait_status(sk_config* cfg, unsigned int seq, hipStream_t st) { return wait_status(cfg, seq, st); }
 
 // core march on sorted unique lags already on the device (src/adaptive.jl:110-202)
 static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0, double ks0, double* d_ks, double* d_errs,
@@ -634,6 +641,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   cfg->c = (args->dim == 1 ? 2.0 : 2.0 * M_PI) * (args->derivative ? -2.0 * M_PI : 1.0) * (args->logw ? -1.0 : 1.0);
   cfg->sdf.kind = args->sdf_kind;
   std::memcpy(cfg->sdf.prm, args->sdf_params, sizeof(cfg->sdf.prm));
+  cfg->sdf.prm[7] = (double)args->sdf_dparam;
   cfg->sdf.f = args->f;
   cfg->sdf.ctx = args->f_ctx;
   cfg->dsdf = cfg->sdf;  // only ever called for callback SDFs (the catalogue's derivative lives on the device)
@@ -661,6 +669,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   dc.alpha = args->alpha; dc.p = cfg->p; dc.c = cfg->c; dc.tol = args->tol; dc.tail = args->tail;
   dc.sdf_kind = args->sdf_kind;
   std::memcpy(dc.sdf_prm, args->sdf_params, sizeof(dc.sdf_prm));
+  dc.sdf_prm[7] = (double)args->sdf_dparam;
   if (dc.sdf_kind == SK_SDF_MATERN) {  // device fast path for half-integer exponents (sdf_eval_dev)
     const double h = 2.0 * (dc.sdf_prm[2] + 0.5 * dc.sdf_prm[3]);
     dc.sdf_prm[4] = (h == std::floor(h) && h >= 1.0 && h <= 64.0) ? h : 0.0;
@@ -748,7 +757,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   if (hipHostMalloc((void**)&cfg->h_status, sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&db.host_status, cfg->h_status, 0) != hipSuccess ||
       hipHostMalloc((void**)&cfg->h_nuniq, sizeof(long long)) != hipSuccess ||
-      hipHostMalloc((void**)&cfg->h_scal, 8 * sizeof(double)) != hipSuccess) {
+      hipHostMalloc((void**)&cfg->h_scal, 32 * sizeof(double)) != hipSuccess) {
     sk_config_destroy(cfg);
     return fail(SK_EHIP, "hipHostMalloc failed");
   }
@@ -861,6 +870,12 @@ void sk_config_destroy(sk_config* cfg) {
   if (cfg->h_in) hipHostFree(cfg->h_in);
   if (cfg->h_out) hipHostFree(cfg->h_out);
   if (cfg->d_aux) hipFree(cfg->d_aux);
+  if (cfg->d_joint) hipFree(cfg->d_joint);
+  for (int q = 0; q <= kJointTr; ++q) {
+    if (cfg->plan_joint[q]) rocfft_plan_destroy(cfg->plan_joint[q]);
+    if (cfg->info_joint[q]) rocfft_execution_info_destroy(cfg->info_joint[q]);
+    if (cfg->fft_work_joint[q]) hipFree(cfg->fft_work_joint[q]);
+  }
   for (hipEvent_t e : cfg->cp_events) hipEventDestroy(e);
   if (cfg->d_lags) hipFree(cfg->d_lags);
   if (cfg->d_plags) hipFree(cfg->d_plags);
@@ -1316,6 +1331,7 @@ int sk_host_compute_k0(const sk_config_args* a, double* k0) {
   SdfHost f;
   f.kind = a->sdf_kind;
   std::memcpy(f.prm, a->sdf_params, sizeof(f.prm));
+  f.prm[7] = (double)a->sdf_dparam;
   f.f = a->f;
   f.ctx = a->f_ctx;
   double p = -a->alpha + (a->dim == 1 ? 0.0 : a->dim / 2.0) + (a->derivative ? 1.0 : 0.0);
@@ -1334,6 +1350,7 @@ int sk_host_compute_k0_part(const sk_config_args* a, double t_lo, double t_hi, d
   SdfHost f;
   f.kind = a->sdf_kind;
   std::memcpy(f.prm, a->sdf_params, sizeof(f.prm));
+  f.prm[7] = (double)a->sdf_dparam;
   f.f = a->f;
   f.ctx = a->f_ctx;
   double p = -a->alpha + (a->dim == 1 ? 0.0 : a->dim / 2.0) + (a->derivative ? 1.0 : 0.0);

@@ -64,6 +64,12 @@ struct sk_config {
   std::vector<size_t> chunk_edge;            // chunk boundaries of the transfer in progress
   std::vector<hipEvent_t> cp_events;         // one per download chunk
   double host_timing[4] = {0, 0, 0, 0};      // last sk_kernel_values call: upload, march, download, total (ms)
+  // joint march (sk_joint.cpp): grow-only buffers, one rocFFT plan per number of raw transforms
+  void* d_joint = nullptr;
+  size_t joint_bytes = 0;
+  rocfft_plan plan_joint[kJointTr + 1] = {};
+  rocfft_execution_info info_joint[kJointTr + 1] = {};
+  void* fft_work_joint[kJointTr + 1] = {};
   // grow-only device scratch of the multi / pairs / dense entries (points, index pairs, per-config results)
   void* d_aux = nullptr;
   size_t aux_bytes = 0;

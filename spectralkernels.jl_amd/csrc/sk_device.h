@@ -37,6 +37,34 @@ struct HankelPlan {
   double pa, pb;               // the (sub)panel, for bounding the near prefix by whole sub-panels
 };
 
+// Joint march of several integrands on one lag set (sk_kernel_values_joint; src/derivatives.jl:51-112 calls
+// kernel_values once per integrand on the same warp_lags).  Integrand t has its own running sums, tail fit and
+// outputs; a raw transform is one set of source strengths through the shared spread / FFT / interpolation.
+constexpr int kJointMax = 8;   // integrands per march
+constexpr int kJointTr = 10;   // raw transforms per (sub)panel (a logw integrand takes two)
+struct JointTr {
+  int sdf_kind;    // catalogue SDF (prm[7]: parameter-derivative index, prm[4]: half-integer fast path)
+  int xw;          // extra factor w (the K' integrand: p = p_base + 1, src/adaptive.jl:42)
+  int logmode;     // 0: none; 1 / 2: slots A / B of a logw integrand (src/quadrature.jl:186-228, :243)
+  int imag;        // take the imaginary part (sin kernel) instead of the real part (cos kernel)
+  int out;         // integrand this transform feeds
+  int pad;
+  double prm[8];
+};
+struct JointSpec {
+  int nt, ntr;
+  double c[kJointMax];        // scale of integrand t (src/adaptive.jl:43-45)
+  int tail_tr[kJointMax];     // transform whose plain SDF |f(b)| drives integrand t's tail fit (src/adaptive.jl:204-220)
+  JointTr tr[kJointTr];
+};
+// per-call buffers of a joint march, integrand-major with stride n (lags)
+struct JointBufs {
+  double* accK[2]; double* accE[2]; double* P[2];  // nt x n each
+  double* ks; double* errs;                        // nt x n: outputs (sorted-unique order)
+  double2* fft; double2* fft_out;                  // ntr x 4 x n1 spread grids / their transforms
+  double ks0[kJointMax];                           // values stored at x == 0
+};
+
 // Per-config constants, passed to kernels by value.
 struct DevConst {
   // quadrature
@@ -44,6 +72,7 @@ struct DevConst {
   int dim, derivative, crit0, has_tail, logw;
   double alpha, p, c, tol, tail;
   int sdf_kind;        // 0 = values supplied by host callback
+  int joint_nt;        // > 0: joint march with this many integrands (tail fits per integrand)
   double sdf_prm[8];
   // NUFFT geometry (fixed per config): spread grid n1, FFT length n2, width w
   int64_t n1, n2;
@@ -100,6 +129,9 @@ struct DevState {
   long long n, ix1, hi, hi_prev;  // active lags are [ix1, hi)
   long long rhi_for;    // value of hi for which pp.r_hi / pp.inv_rc were loaded (-1: none)
   TailScalars tail;     // of the current outer panel
+  TailScalars jtail[kJointMax];  // joint march: per integrand (jcrit: its effective criteria so far)
+  int jcrit[kJointMax];
+  double jB0;           // joint march: boundary factor of the logw integrand on the current [0, b] panel
   // confirmed running sums live in acc buffer `conf` (valid iff has_acc); every evaluation writes
   // the optimistic sums into the other buffer, an accepted panel flips `conf`.  P (the current
   // outer panel's accepted sub-panel sums, src/adaptive.jl:183-198 uses them) is only
@@ -115,7 +147,7 @@ struct DevState {
 
 // integrand handed to the panel rule (src/quadrature.jl:184-247): S(w) [times w^p log(w) factors as the
 // panel requires], or the two integrands of the integration-by-parts formula for logw on [0, b]
-enum { SK_G_DEFAULT = 0, SK_G_LOGA = 1, SK_G_LOGB = 2 };
+enum { SK_G_DEFAULT = 0, SK_G_LOGA = 1, SK_G_LOGB = 2, SK_G_WEIGHT = 3 /* joint march: Gauss weight w^p only, stored with the node */ };
 // what an evaluation kernel does with the panel sums: the usual epilogue, or store them raw (logw passes A, B)
 enum { SK_RAW_NONE = 0, SK_RAW_A = 1, SK_RAW_B = 2 };
 
@@ -191,6 +223,12 @@ void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& d
 void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, int raw, hipStream_t st);
 void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                     unsigned int seq, hipStream_t st);
+
+// joint march (sk_joint_kernels.inc)
+void launch_joint_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const JointSpec& js, const JointBufs& jb,
+                         int slot, hipStream_t st);
+void launch_joint_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const JointSpec& js, const JointBufs& jb,
+                         int slot, long long n, hipStream_t st);
 
 // seam kernels for sk_panel_sums
 void launch_seam_spread(const DevConst& dc, const double* nodes, const double* coef, int64_t M, double Cx, double X,

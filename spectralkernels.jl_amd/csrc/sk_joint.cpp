@@ -1,0 +1,212 @@
+// sk_joint.cpp -- sk_kernel_values_joint: several integrands on one lag set in ONE panel march.
+// Host driver of the kernels in sk_joint_kernels.inc; the schedule rule and what is shared are described there.
+// Counterpart of the call pattern of src/derivatives.jl:51-112 (gen_kernel_jacobian): kernel_sdf_derivatives (one
+// kernel_values per dS/dtheta_j), kernel_warping_gradients (derivative=true), kernel_singularity_derivative
+// (logw=true), all on the same warp_lags with the same k0.
+#include <cmath>
+#include <cstring>
+#include "sk_config.h"
+
+namespace sk {
+int joint_wait_status(sk_config* cfg, unsigned int seq, hipStream_t st);  // sk_api.cpp (wait_status)
+}
+
+namespace {
+
+int ensure_dev_buf(void** buf, size_t* have, size_t bytes) {
+  if (bytes <= *have) return SK_OK;
+  if (*buf) HIPCHK(hipFree(*buf));
+  *buf = nullptr;
+  *have = 0;
+  HIPCHK(hipMalloc(buf, bytes + bytes / 8));
+  *have = bytes + bytes / 8;
+  return SK_OK;
+}
+
+size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, double k0,
+                                      const int* param_derivative, double* vals_out, double* errs_out) {
+  if (!cfgs || ncfg == 0 || !cfgs[0]) return fail(SK_EINVAL, "null config");
+  if (ncfg > (size_t)kJointMax) return fail(SK_EINVAL, "at most 8 integrands per joint march");
+  sk_config* c0 = cfgs[0];
+  if (c0->args.derivative || c0->args.logw)
+    return fail(SK_EINVAL, "joint march: the first config must be the plain kernel (it provides the shared nodes)");
+  // ---- the integrands must share everything but the integrand itself
+  JointSpec js;
+  std::memset(&js, 0, sizeof(js));
+  js.nt = (int)ncfg;
+  for (size_t t = 0; t < ncfg; ++t) {
+    const sk_config* c = cfgs[t];
+    if (!c) return fail(SK_EINVAL, "null config");
+    const sk_config_args& a = c->args;
+    if (c->device != c0->device) return fail(SK_EINVAL, "joint march: configs must live on one device");
+    if (a.dim != 1) return fail(SK_EUNSUPPORTED, "joint march: dim must be 1");
+    if (a.sdf_kind == SK_SDF_CALLBACK) return fail(SK_EUNSUPPORTED, "joint march: catalogue SDFs only (the integrands are evaluated on the device)");
+    if (c->m != c0->m || c->k != c0->k || a.tol != c0->args.tol || a.alpha != c0->args.alpha || a.criteria != c0->args.criteria ||
+        a.has_tail != c0->args.has_tail || (a.has_tail && a.tail != c0->args.tail) || c->dc.w != c0->dc.w)
+      return fail(SK_EINVAL, "joint march: quadspec, tol, alpha, convergence_criteria, tail and NUFFT width must agree");
+    if (a.logw && a.sdf_dparam) return fail(SK_EUNSUPPORTED, "joint march: logw with a parameter-derivative integrand");
+    const int ntr_needed = a.logw ? 2 : 1;
+    if (js.ntr + ntr_needed > kJointTr) return fail(SK_EINVAL, "joint march: too many raw transforms");
+    js.c[t] = c->c;
+    js.tail_tr[t] = js.ntr;
+    for (int q = 0; q < ntr_needed; ++q) {
+      JointTr& tr = js.tr[js.ntr++];
+      tr.sdf_kind = a.sdf_kind;
+      std::memcpy(tr.prm, c->dc.sdf_prm, sizeof(tr.prm));
+      tr.xw = a.derivative ? 1 : 0;                      // p = p_base + 1 (src/adaptive.jl:42)
+      tr.logmode = a.logw ? (q == 0 ? 1 : 2) : 0;
+      tr.imag = a.logw ? q : (a.derivative ? 1 : 0);     // :sin for K' and for slot B (src/quadrature.jl:177,198)
+      tr.out = (int)t;
+    }
+  }
+  if (n == 0) return SK_OK;
+  if (n > (size_t)0x7fffffff) return fail(SK_EINVAL, "at most 2^31-1 lags per call");
+  HIPCHK(hipSetDevice(c0->device));
+  hipStream_t st = c0->own_stream;
+  const int nt = js.nt, ntr = js.ntr;
+  const int64_t n1 = c0->dc.n1;
+  // ---- values at x == 0 (src/adaptive.jl:134-145)
+  JointBufs jb;
+  std::memset(&jb, 0, sizeof(jb));
+  for (int t = 0; t < nt; ++t) {
+    double v = k0;
+    if (cfgs[t]->args.derivative) v = 0.0;
+    else if (param_derivative && param_derivative[t]) {
+      int rc = sk_compute_k0(cfgs[t], &v);
+      if (rc) return rc;
+    }
+    jb.ks0[t] = v;
+  }
+  // ---- device buffers (grow-only, owned by the first config)
+  const size_t a8 = a256(n * 8);
+  const size_t tb = sort_unique_temp_bytes((long long)n);
+  const size_t fft_b = a256((size_t)ntr * 4 * n1 * sizeof(double2));
+  const size_t need = 3 * a8 + tb + 512 + (size_t)(8 * nt + 2) * a8 + 2 * fft_b;
+  int rc = ensure_dev_buf(&c0->d_joint, &c0->joint_bytes, need);
+  if (rc) return rc;
+  char* p = (char*)c0->d_joint;
+  double* d_xs = (double*)p; p += a8;
+  double* uxs = (double*)p; p += a8;
+  long long* inv = (long long*)p; p += a8;
+  long long* d_nu = (long long*)p; p += 256;
+  void* tmp = p; p += a256(tb) + 256;
+  double* big = (double*)p; p += (size_t)(8 * nt + 2) * a8;
+  jb.fft = (double2*)p; p += fft_b;
+  jb.fft_out = (double2*)p;
+  // ---- lags: staged upload, one sort + dedup for all integrands (src/adaptive.jl:99-120)
+  int order = SK_ORDER_UNKNOWN;
+  rc = h2d_doubles(c0, d_xs, xs, n, st, &order);
+  if (rc) return rc;
+  if (order == SK_ORDER_INVALID) return fail(SK_EINVAL, "lags must be non-negative and finite");
+  long long nu = (long long)n;
+  const bool sorted = (order == SK_ORDER_SORTED);
+  const double* lags = d_xs;
+  if (!sorted) {
+    sort_unique(d_xs, (long long)n, uxs, inv, d_nu, tmp, tb, st);
+    if (hipMemcpyAsync(c0->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return fail(SK_EHIP, "sort failed");
+    nu = *c0->h_nuniq;
+    lags = uxs;
+  }
+  const size_t sn = (size_t)nu;
+  double* q = big;
+  jb.accK[0] = q; q += (size_t)nt * sn; jb.accK[1] = q; q += (size_t)nt * sn;
+  jb.accE[0] = q; q += (size_t)nt * sn; jb.accE[1] = q; q += (size_t)nt * sn;
+  jb.P[0] = q; q += (size_t)nt * sn; jb.P[1] = q; q += (size_t)nt * sn;
+  jb.ks = q; q += (size_t)nt * sn; jb.errs = q; q += (size_t)nt * sn;
+  double* gk = q;  // gathered values, then n doubles later the gathered error estimates (unsorted input)
+  // ---- rocFFT plan for this number of transforms
+  if (!c0->plan_joint[ntr]) {
+    size_t len[1] = {(size_t)n1};
+    FFTCHK(rocfft_plan_create(&c0->plan_joint[ntr], rocfft_placement_notinplace, rocfft_transform_type_complex_inverse,
+                              rocfft_precision_double, 1, len, (size_t)4 * ntr, nullptr));
+    size_t wb = 0;
+    rocfft_plan_get_work_buffer_size(c0->plan_joint[ntr], &wb);
+    FFTCHK(rocfft_execution_info_create(&c0->info_joint[ntr]));
+    if (wb) {
+      HIPCHK(hipMalloc(&c0->fft_work_joint[ntr], wb));
+      FFTCHK(rocfft_execution_info_set_work_buffer(c0->info_joint[ntr], c0->fft_work_joint[ntr], wb));
+    }
+  }
+  FFTCHK(rocfft_execution_info_set_stream(c0->info_joint[ntr], st));
+  // ---- the march (device-resident; the host sees the state once per round of R steps, as run_core)
+  DevConst dcj = c0->dc;
+  dcj.joint_nt = nt;
+  DevBuffers db = c0->db;
+  db.xs = lags;
+  db.ks = jb.ks;
+  db.errs = jb.errs;
+  db.check_input = 0;
+  if (order == SK_ORDER_UNKNOWN) launch_check_sorted(lags, nu, db.flags, st);  // pinned input: not looked at yet
+  std::memset(&c0->stats, 0, sizeof(c0->stats));
+  c0->stats.n_unique = nu;
+  const DevState* hs = &c0->h_status->state;
+  int t = 0, mode = SK_MODE_INIT, R = 2;
+  for (;;) {
+    for (int r = 0; r < R; ++r) {
+      launch_gen(dcj, db, mode, t, nu, k0, jb.ks0[0], SK_G_WEIGHT, st);
+      launch_joint_spread(dcj, c0->d_ec, db, js, jb, t & 1, st);
+      {
+        void* in[1] = {jb.fft};
+        void* out[1] = {jb.fft_out};
+        FFTCHK(rocfft_execute(c0->plan_joint[ntr], in, out, c0->info_joint[ntr]));
+      }
+      launch_joint_interp(dcj, c0->d_ec, db, js, jb, t & 1, nu, st);
+      ++t;
+      mode = SK_MODE_TRANSITION;
+      c0->stats.n_steps_launched++;
+    }
+    const unsigned int seq = ++c0->seq;
+    launch_advance(dcj, db, mode, t, nu, k0, jb.ks0[0], seq, st);
+    rc = joint_wait_status(c0, seq, st);
+    if (rc) return rc;
+    if (order == SK_ORDER_UNKNOWN && (c0->h_status->flags[0] || c0->h_status->flags[1])) {
+      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(hipMemsetAsync(c0->db.flags, 0, 2 * sizeof(int), st));
+      return fail(SK_EINVAL, c0->h_status->flags[1] ? "lags must be non-negative and finite"
+                                                    : "joint march on pinned input needs strictly increasing lags");
+    }
+    if (hs->done) break;
+    mode = SK_MODE_ASIS;
+    R = R < 16 ? 2 * R : 16;
+  }
+  HIPCHK(hipGetLastError());
+  c0->stats.n_outer = hs->n_outer;
+  c0->stats.n_panels = hs->n_panels;
+  c0->stats.n_accepted = hs->n_accepted;
+  c0->stats.sum_active = hs->sum_active;
+  c0->stats.last_b = hs->b;
+  c0->trace_len = (size_t)hs->trace_len;
+  c0->trace_valid = false;
+  if (hs->done < 0) {
+    const int code = -hs->done;
+    return fail(code, code == SK_ESUBDIVIDE ? "The sub-interval (a, b) has been split too many times (b - a < 1e-16). Exiting to avoid infinite splitting."
+                      : (code == SK_ENAN ? "NaN detected in panel integral..." : "device-side failure in the joint march"));
+  }
+  // ---- values at x == 0 of the other integrands (integrand 0's were written by the march's first step)
+  if (hs->ix1 == 1) {
+    for (int tt = 1; tt < nt; ++tt) {
+      c0->h_scal[2 * tt] = jb.ks0[tt];
+      c0->h_scal[2 * tt + 1] = std::nan("");
+      HIPCHK(hipMemcpyAsync(jb.ks + (size_t)tt * sn, &c0->h_scal[2 * tt], sizeof(double), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(jb.errs + (size_t)tt * sn, &c0->h_scal[2 * tt + 1], sizeof(double), hipMemcpyHostToDevice, st));
+    }
+  }
+  // ---- results back, integrand by integrand
+  for (int tt = 0; tt < nt; ++tt) {
+    if (sorted) {
+      rc = d2h_doubles(c0, vals_out + (size_t)tt * n, jb.ks + (size_t)tt * sn, n, st);
+      if (!rc) rc = d2h_doubles(c0, errs_out + (size_t)tt * n, jb.errs + (size_t)tt * sn, n, st);
+    } else {
+      launch_gather(jb.ks + (size_t)tt * sn, jb.errs + (size_t)tt * sn, inv, (long long)n, gk, gk + n, st);
+      rc = d2h_doubles2(c0, vals_out + (size_t)tt * n, errs_out + (size_t)tt * n, gk, n, st);
+    }
+    if (rc) return rc;
+  }
+  return SK_OK;
+}

@@ -13,10 +13,24 @@
 namespace sk {
 
 double sdf_eval_host(int kind, const double* p, double w) {
+  const int dparam = (int)p[7];  // 0: the SDF; j >= 1: d/d(parameter j - 1), as sdf_eval_dev
   switch (kind) {
-    case SK_SDF_MATERN: return p[0] * std::pow(p[1] * p[1] + w * w, -p[2] - p[3] / 2.0);
-    case SK_SDF_EXPONENTIAL: return std::exp(-p[0] * std::fabs(w));
-    case SK_SDF_GAUSSIAN: return std::exp(-(w * w) / (p[0] * p[0]));
+    case SK_SDF_MATERN: {
+      const double x = p[1] * p[1] + w * w, e = -p[2] - p[3] / 2.0, S = p[0] * std::pow(x, e);
+      if (dparam == 0) return S;
+      if (dparam == 1) return S / p[0];
+      if (dparam == 2) return S * e * 2.0 * p[1] / x;
+      if (dparam == 3) return -S * std::log(x);
+      return NAN;
+    }
+    case SK_SDF_EXPONENTIAL: {
+      const double S = std::exp(-p[0] * std::fabs(w));
+      return dparam == 0 ? S : (dparam == 1 ? -std::fabs(w) * S : NAN);
+    }
+    case SK_SDF_GAUSSIAN: {
+      const double S = std::exp(-(w * w) / (p[0] * p[0]));
+      return dparam == 0 ? S : (dparam == 1 ? S * 2.0 * w * w / (p[0] * p[0] * p[0]) : NAN);
+    }
     default: return NAN;
   }
 }

@@ -62,24 +62,40 @@ __device__ __forceinline__ double2 cis_turns_prod(double a, double b) {
 }
 
 __device__ __forceinline__ double sdf_eval_dev(int kind, const double* prm, double w) {
+  // prm[7] = 0: the SDF itself; j >= 1: its derivative with respect to catalogue parameter j - 1 (the integrands of
+  // kernel_sdf_derivatives, src/derivatives.jl:61-72)
+  const int dparam = (int)prm[7];
   switch (kind) {
     case SK_SDF_MATERN: {
       const double x = prm[1] * prm[1] + w * w;
       // prm[4] (set by sk_config_create): 2 (nu + d/2) when that is an integer <= 64, else 0.  Half-integer
       // powers by sqrt and repeated squaring (~2 ulp) instead of the generic pow (~250 instructions).
       const int h = (int)prm[4];
+      double S;
       if (h > 0) {
         double b = (h & 1) ? sqrt(x) : 1.0, sq = x, r = 1.0;
         for (int e = h >> 1; e > 0; e >>= 1) {
           if (e & 1) r *= sq;
           sq *= sq;
         }
-        return prm[0] / (r * b);
+        S = prm[0] / (r * b);
+      } else {
+        S = prm[0] * pow(x, -prm[2] - prm[3] * 0.5);
       }
-      return prm[0] * pow(x, -prm[2] - prm[3] * 0.5);
+      if (dparam == 0) return S;
+      if (dparam == 1) return S / prm[0];                                        // d/dphi
+      if (dparam == 2) return S * (-prm[2] - prm[3] * 0.5) * 2.0 * prm[1] / x;    // d/drho
+      if (dparam == 3) return -S * log(x);                                       // d/dnu
+      return __builtin_nan("");
     }
-    case SK_SDF_EXPONENTIAL: return exp(-prm[0] * fabs(w));
-    case SK_SDF_GAUSSIAN: return exp(-(w * w) / (prm[0] * prm[0]));
+    case SK_SDF_EXPONENTIAL: {
+      const double S = exp(-prm[0] * fabs(w));
+      return dparam == 0 ? S : (dparam == 1 ? -fabs(w) * S : __builtin_nan(""));
+    }
+    case SK_SDF_GAUSSIAN: {
+      const double S = exp(-(w * w) / (prm[0] * prm[0]));
+      return dparam == 0 ? S : (dparam == 1 ? S * 2.0 * w * w / (prm[0] * prm[0] * prm[0]) : __builtin_nan(""));
+    }
     default: return __builtin_nan("");
   }
 }
@@ -132,15 +148,14 @@ __device__ void set_panel(DevState& s, const DevConst& dc, const double* xs, dou
 
 // src/adaptive.jl:204-220 with all 1000 sample points equal to b (minimum-norm least squares),
 // followed by the target-independent factors of truncation_error_estimate (:222-229).
-__device__ void tail_scalars(DevState& s, const DevConst& dc) {
+__device__ TailScalars tail_of(const DevConst& dc, double b, double fb_abs, int crit) {
   TailScalars t;
-  t.crit = s.crit;
+  t.crit = crit;
   t.t1 = 0.0;
   t.t2num = 0.0;
   t.pad = 0;
-  if (s.crit != SK_CRIT_PANEL) {
-    const double b = s.b;
-    const double fb = fabs(s.fb);
+  if (crit != SK_CRIT_PANEL) {
+    const double fb = fb_abs;
     double d;
     if (!dc.has_tail) {
       double L = log(b), y = log(fb);
@@ -165,8 +180,9 @@ __device__ void tail_scalars(DevState& s, const DevConst& dc) {
       t.t2num = c * (bd * bhalf) / (2.0 * SK_PI);
     }
   }
-  s.tail = t;
+  return t;
 }
+__device__ void tail_scalars(DevState& s, const DevConst& dc) { s.tail = tail_of(dc, s.b, fabs(s.fb), s.crit); }
 
 // src/adaptive.jl:149-152: next outer panel or finish.
 __device__ void setup_outer(DevState& s, const DevConst& dc, const double* xs) {
@@ -222,6 +238,7 @@ __device__ void init_state(DevState& s, const DevConst& dc, const DevBuffers& db
   s.hi = n;
   s.ix1 = (n > 0 && db.xs[0] == 0.0) ? 1 : 0;  // src/adaptive.jl:132-133
   s.crit = dc.crit0;
+  for (int q = 0; q < kJointMax; ++q) s.jcrit[q] = dc.crit0;
   s.hi_new = (unsigned long long)s.ix1;
   setup_outer(s, dc, db.xs);
 }
@@ -270,6 +287,7 @@ __device__ void transition(DevState& s, const DevConst& dc, const DevBuffers& db
       // outer panel complete: src/adaptive.jl:168-199
       s.p_valid = 0;
       s.crit = s.tail.crit;  // a NaN tail fit switches to :panel for the rest of the call
+      for (int q = 0; q < dc.joint_nt; ++q) s.jcrit[q] = s.jtail[q].crit;
       s.hi = (long long)s.hi_new;
       setup_outer(s, dc, db.xs);
     }
@@ -508,7 +526,9 @@ __global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mod
     wq = wt[q] * bmad2 * (dc.p == 0.0 ? 1.0 : pow(w, dc.p));
   }
   double f;
-  if (dc.sdf_kind == SK_SDF_CALLBACK) {
+  if (g == SK_G_WEIGHT) {
+    f = 1.0;  // joint march: the integrands are applied while spreading (k_spread_joint)
+  } else if (dc.sdf_kind == SK_SDF_CALLBACK) {
     f = db.fvals[jg];  // the host evaluated the whole integrand (log factors included)
   } else {
     f = sdf_eval_dev(dc.sdf_kind, dc.sdf_prm, w);
@@ -519,7 +539,7 @@ __global__ void __launch_bounds__(256) k_gen(DevConst dc, DevBuffers db, int mod
     }
   }
   const double cj = wq * f;
-  if (dc.dim > 1) {  // Hankel path: k_bessel sums c_j J_nu(2 pi w_j r) directly, it needs the node itself
+  if (dc.dim > 1 || g == SK_G_WEIGHT) {  // Hankel path: k_bessel sums c_j J_nu(2 pi w_j r) directly, it needs the node itself
     db.src[jg] = make_double2(cj, w);
     return;
   }
@@ -2204,5 +2224,7 @@ void launch_gather(const double* ks, const double* errs, const long long* inv, l
                    hipStream_t st) {
   hipLaunchKernelGGL(k_gather, dim3(nblk(n, 256)), dim3(256), 0, st, ks, errs, inv, n, vals, eo);
 }
+
+#include "sk_joint_kernels.inc"
 
 }  // namespace sk
