@@ -74,6 +74,53 @@ class SDF:
 
 _CRIT = {"both": 0, "panel": 1, "tails": 2}
 
+_PROBES = np.array([0.0, 1e-3, 0.017, 0.13, 0.71, 1.0, 2.3, 9.1, 47.0, 3.1e2, 2.2e3])
+
+
+def recognize_sdf(fn, dim=1, rtol=1e-12):
+    """Is the callable one of the catalogue families?  README-style scripts pass closures such as
+    `w -> (1 + w^2)^-2` (README.md:26); evaluated through the batched host callback they cost one host round trip
+    per panel.  A closure that reproduces phi (rho^2 + w^2)^-e, exp(-a |w|) or exp(-(w/a)^2) to `rtol` at eleven
+    probe frequencies over six decades (parameters solved from three of them, the rest verify) is evaluated on the
+    device instead.  Returns an SDF or None.  AdaptiveKernelConfig(..., sdf="callback") switches this off."""
+    try:
+        v = np.array([float(fn(float(w))) for w in _PROBES])
+    except Exception:
+        return None
+    if not np.all(np.isfinite(v)) or not np.all(v[:6] > 0) or np.any(v < 0):
+        return None
+    w = _PROBES
+    ok = lambda model: bool(np.all(np.abs(model - v) <= rtol * np.abs(v) + 1e-300))
+    # exponential: log f linear in |w|
+    a = -np.log(v[5] / v[0])
+    if a > 0 and abs(v[0] - 1.0) <= rtol and ok(np.exp(-a * w)):
+        return SDF.exponential(a)
+    # gaussian: log f linear in w^2
+    g = -np.log(v[5] / v[0])
+    if g > 0 and abs(v[0] - 1.0) <= rtol and ok(np.exp(-g * w * w)):
+        return SDF.gaussian(1.0 / np.sqrt(g))
+    # Matern form: f(w)/f(0) = (1 + w^2/rho^2)^-e; rho^2 from the ratio of two log-ratios (monotone in rho^2)
+    if not np.all(v > 0):
+        return None
+    L1, L2 = np.log(v[0] / v[5]), np.log(v[0] / v[7])
+    if L1 > 0 and L2 > L1:
+        target = L1 / L2
+        ratio = lambda q: np.log1p(w[5] ** 2 / q) / np.log1p(w[7] ** 2 / q)  # decreasing in q = rho^2
+        lo, hi = 1e-12, 1e12
+        if ratio(hi) < target < ratio(lo):
+            for _ in range(200):
+                mid = np.sqrt(lo * hi)
+                lo, hi = (mid, hi) if ratio(mid) > target else (lo, mid)
+            rho = np.sqrt(np.sqrt(lo * hi))
+            e = L1 / np.log1p(w[5] ** 2 / (rho * rho))
+            snap = lambda x: float("%.13g" % x)  # the closure's literals, not their 1e-16 echoes (2 e integer: fast path)
+            for rr, ee in ((snap(rho), snap(e)), (rho, e)):
+                phi = v[0] * rr ** (2 * ee)
+                for ph in (snap(phi), phi):
+                    if ok(ph * (rr * rr + w * w) ** (-ee)):
+                        return SDF.matern(ph, rr, ee - dim / 2.0, dim)
+    return None
+
 
 def _check(code):
     if code not in (L.SK_OK, L.SK_WARN_QUADSPEC):
@@ -82,9 +129,10 @@ def _check(code):
 
 
 def _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, tail, quadspec, device, nufft_width,
-               hankel_min_lags=0):
+               hankel_min_lags=0, sdf="auto"):
     if not isinstance(f, SDF):
-        f = SDF.callback(f)
+        rec = recognize_sdf(f, dim) if sdf == "auto" else None
+        f = rec if rec is not None else SDF.callback(f)
     if convergence_criteria not in _CRIT:
         raise SpectralKernelsError(L.SK_EINVAL, "Argument convergence_criteria must be one of :panel, :tails, :both.")
     a = L.ConfigArgs()
@@ -132,11 +180,12 @@ class AdaptiveKernelConfig:
 
     def __init__(self, f, df=None, dim=1, alpha=0.0, tol=1e-8, derivative=False, logw=False,
                  convergence_criteria="both", tail=None, quadspec=(2 ** 12, 2 ** 4), device=-1, nufft_width=0,
-                 hankel_min_lags=0):
+                 hankel_min_lags=0, sdf="auto"):
         self._h = None
         lib = L.load()
+        self.df, self._device = df, device
         args, self._keep, self.f = _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, tail,
-                                              quadspec, device, nufft_width, hankel_min_lags)
+                                              quadspec, device, nufft_width, hankel_min_lags, sdf)
         self._args = args
         h = C.c_void_p()
         code = _check(lib.sk_config_create(C.byref(h), C.byref(args)))
@@ -196,6 +245,20 @@ class AdaptiveKernelConfig:
         n = C.c_size_t()
         _check(L.load().sk_last_trace(self._h, rec.ctypes.data_as(C.c_void_p), 4096, C.byref(n)))
         return [dict(a=r[0], b=r[1], max_err=r[2], n_active=int(r[3]), accepted=bool(r[4])) for r in rec[:n.value]]
+
+
+def gen_derivative_config(cfg):
+    """gen_derivative_config(cfg) -- src/adaptive.jl:61-66: the same integrand with derivative=true."""
+    return AdaptiveKernelConfig(cfg.f, df=cfg.df, derivative=True, dim=cfg.dim, alpha=cfg.alpha, tol=cfg.tol,
+                                logw=cfg.logw, tail=cfg.tail, convergence_criteria=cfg.convergence_criteria,
+                                quadspec=cfg.quadspec, device=cfg._device)
+
+
+def gen_new_sdf_config(cfg, new_f, alpha=None):
+    """gen_new_sdf_config(cfg, new_f, alpha=cfg.alpha) -- src/adaptive.jl:69-72: only df, dim, alpha and tol carry
+    over (quadspec, criteria, tail, logw, derivative fall back to their defaults, as in the reference)."""
+    return AdaptiveKernelConfig(new_f, df=cfg.df, dim=cfg.dim, alpha=cfg.alpha if alpha is None else alpha, tol=cfg.tol,
+                                device=cfg._device)
 
 
 def compute_k0(config):

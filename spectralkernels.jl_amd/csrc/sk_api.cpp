@@ -2,6 +2,7 @@
 // of the device-resident panel march.  Host-side mirror of src/adaptive.jl:24-108.
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -207,12 +208,41 @@ static const bool g_debug_sync = getenv("SK_DEBUG_SYNC") != nullptr;
 static const bool g_no_fuse = getenv("SK_NO_FUSE") != nullptr;  // diagnostics: separate k_gen and k_spread launches
 static const char* const k_names[SK_K_COUNT] = {"k_gen", "k_spread", "rocfft", "k_interp", "k_advance"};
 
+// SK_ROCTX=1: roctx ranges named after the reference's @timeit sections (src/adaptive.jl:156-199,
+// src/quadrature.jl:99-160) around the launches that do their work, for rocprofv3 --marker-trace.  The library is
+// looked up at run time (librocprofiler-sdk-roctx, then libroctx64): no link-time dependency, no cost when off.
+static const char* const k_roctx_names[SK_K_COUNT] = {
+    "update quadrature buffers", "FINUFFT call / spread", "FINUFFT call / fft",
+    "FINUFFT call / interpolate + add panels to integral + check convergence", "interval integral / step state"};
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (!getenv("SK_ROCTX")) return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) return;
+      }
+    }
+    push = nullptr;
+    pop = nullptr;
+  }
+};
+static Roctx g_roctx;
+struct RoctxRange {
+  explicit RoctxRange(const char* name) { if (g_roctx.push) g_roctx.push(name); }
+  ~RoctxRange() { if (g_roctx.pop) g_roctx.pop(); }
+};
+
 struct EvScope {
   sk_config* cfg;
   hipStream_t st;
   int kid;
   hipEvent_t a, b;
   EvScope(sk_config* c, hipStream_t s, int k) : cfg(c), st(s), kid(k) {
+    if (g_roctx.push) g_roctx.push(k_roctx_names[kid]);
     if (g_debug_sync) fprintf(stderr, "[sk] launch %s\n", k_names[kid]);
     if (cfg->profile) {
       a = ev_get(cfg);
@@ -221,6 +251,7 @@ struct EvScope {
     }
   }
   ~EvScope() {
+    if (g_roctx.pop) g_roctx.pop();
     if (g_debug_sync) {
       hipError_t e = hipStreamSynchronize(st);
       fprintf(stderr, "[sk]   %s -> %s\n", k_names[kid], hipGetErrorString(e));
@@ -959,6 +990,7 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
     if (rc) return rc;
   }
   if (n == 0) return SK_OK;
+  RoctxRange range("kernel_values");
   HIPCHK(hipSetDevice(cfg->device));
   const auto t0 = std::chrono::steady_clock::now();
   // grow-only device staging buffer of the host-array entry (lags, values, errors)

@@ -1,26 +1,82 @@
 # SpectralKernelsHIP.jl -- thin `ccall` shim over libspectralkernels_hip.so.
 #
-# Drop-in for the kernel_values path of SpectralKernels.jl: same constructor keywords as
-# `AdaptiveKernelConfig` (src/adaptive.jl:24-27) and the same `kernel_values(cfg, xs; k0,
-# param_derivative, verbose) -> (vals, errs)` contract (src/adaptive.jl:95-108).  All numerical
-# work happens behind the C ABI declared in include/spectralkernels_hip.h; this file only
-# marshals arguments.  (Julia is not installed in the build container, so this shim is
-# exercised through its line-by-line ctypes mirror spectralkernels.jl_amd/api.py.)
+# Drop-in for the kernel_values path of SpectralKernels.jl: the struct fields and constructor keywords of
+# `AdaptiveKernelConfig` (src/adaptive.jl:2-27), `gen_derivative_config` / `gen_new_sdf_config` (:61-72),
+# `compute_k0` (:74-91) and `kernel_values(cfg, xs; k0, param_derivative, verbose) -> (vals, errs)` (:95-108),
+# i.e. everything the L3 callers use (src/model.jl:75, src/derivatives.jl:56,70,80).  All numerical work happens
+# behind the C ABI declared in include/spectralkernels_hip.h; this file only marshals arguments.  (Julia is not
+# installed in the build container, so this shim is exercised through its line-by-line ctypes mirror
+# spectralkernels.jl_amd/api.py, which the GPU tests drive.)
 module SpectralKernelsHIP
 
-export AdaptiveKernelConfig, kernel_values, kernel_values_multi, kernel_values_pairs, build_dense_cov_matrix, compute_k0, MaternSDF, ExponentialSDF, GaussianSDF
+export AdaptiveKernelConfig, kernel_values, kernel_values!, kernel_values_multi, kernel_values_joint, kernel_values_pairs,
+       build_dense_cov_matrix, compute_k0, gen_derivative_config, gen_new_sdf_config, recognize_sdf, pinned_vector,
+       ShardedKernelConfig, MaternSDF, ExponentialSDF, GaussianSDF, sdf_derivative
 
 const LIB = get(ENV, "SPECTRALKERNELS_HIP_LIB",
                 joinpath(@__DIR__, "..", "libspectralkernels_hip.so"))
 
-# catalogue SDFs evaluated on the device (sk_sdf_kind); any other callable goes through the
-# batched host callback
-struct MaternSDF;      phi::Float64; rho::Float64; nu::Float64; d::Float64; end
-struct ExponentialSDF; a::Float64; end
-struct GaussianSDF;    a::Float64; end
-(s::MaternSDF)(w)      = s.phi*(s.rho^2 + w^2)^(-s.nu - s.d/2)
-(s::ExponentialSDF)(w) = exp(-s.a*abs(w))
-(s::GaussianSDF)(w)    = exp(-(w/s.a)^2)
+# catalogue SDFs evaluated on the device (sk_sdf_kind).  dparam = j >= 1: d/d(parameter j) of the entry, the
+# integrands of kernel_sdf_derivatives (src/derivatives.jl:61-72).  Any other callable is first matched against the
+# catalogue (recognize_sdf) and otherwise evaluated through the batched host callback.
+struct MaternSDF;      phi::Float64; rho::Float64; nu::Float64; d::Float64; dparam::Int; end
+struct ExponentialSDF; a::Float64; dparam::Int; end
+struct GaussianSDF;    a::Float64; dparam::Int; end
+MaternSDF(phi, rho, nu, d=1.0) = MaternSDF(phi, rho, nu, d, 0)
+ExponentialSDF(a=1.0) = ExponentialSDF(a, 0)
+GaussianSDF(a=1.0)    = GaussianSDF(a, 0)
+function (s::MaternSDF)(w)
+  x = s.rho^2 + w^2; e = -s.nu - s.d/2; S = s.phi*x^e
+  s.dparam == 0 ? S : s.dparam == 1 ? S/s.phi : s.dparam == 2 ? S*e*2*s.rho/x : -S*log(x)
+end
+(s::ExponentialSDF)(w) = (S = exp(-s.a*abs(w)); s.dparam == 0 ? S : -abs(w)*S)
+(s::GaussianSDF)(w)    = (S = exp(-(w/s.a)^2);  s.dparam == 0 ? S : S*2*w^2/s.a^3)
+"d/d(parameter j) of a catalogue SDF (1-based: Matern phi, rho, nu; exponential / gaussian a), on the device."
+sdf_derivative(s::MaternSDF, j::Integer)      = MaternSDF(s.phi, s.rho, s.nu, s.d, j)
+sdf_derivative(s::ExponentialSDF, j::Integer) = ExponentialSDF(s.a, j)
+sdf_derivative(s::GaussianSDF, j::Integer)    = GaussianSDF(s.a, j)
+
+const PROBES = [0.0, 1e-3, 0.017, 0.13, 0.71, 1.0, 2.3, 9.1, 47.0, 3.1e2, 2.2e3]
+
+"""
+    recognize_sdf(f, dim=1; rtol=1e-12)
+
+README-style scripts pass closures such as `w -> (1 + w^2)^-2` (README.md:26).  Evaluated through the batched host
+callback they cost one host round trip per panel.  A closure that reproduces `phi (rho^2 + w^2)^-e`, `exp(-a|w|)` or
+`exp(-(w/a)^2)` to `rtol` at eleven probe frequencies over six decades (parameters solved from three of them, the
+others verify) is evaluated on the device instead.  Returns a catalogue SDF or `nothing`.
+`AdaptiveKernelConfig(f; sdf=:callback)` switches the matching off.
+"""
+function recognize_sdf(f, dim=1; rtol=1e-12)
+  v = try Float64[f(w) for w in PROBES] catch; return nothing end
+  (all(isfinite, v) && all(>(0), v[1:6]) && !any(<(0), v)) || return nothing
+  w  = PROBES
+  ok = model -> all(abs.(model .- v) .<= rtol .* abs.(v) .+ 1e-300)
+  a  = -log(v[6]/v[1])
+  (a > 0 && abs(v[1] - 1) <= rtol && ok(exp.(-a .* w)))      && return ExponentialSDF(a)
+  (a > 0 && abs(v[1] - 1) <= rtol && ok(exp.(-a .* w.^2)))   && return GaussianSDF(1/sqrt(a))
+  all(>(0), v) || return nothing
+  (L1, L2) = (log(v[1]/v[6]), log(v[1]/v[8]))
+  (L1 > 0 && L2 > L1) || return nothing
+  target = L1/L2
+  ratio  = q -> log1p(w[6]^2/q)/log1p(w[8]^2/q)               # decreasing in q = rho^2
+  (lo, hi) = (1e-12, 1e12)
+  (ratio(hi) < target < ratio(lo)) || return nothing
+  for _ in 1:200
+    mid = sqrt(lo*hi)
+    (lo, hi) = ratio(mid) > target ? (mid, hi) : (lo, mid)
+  end
+  rho  = sqrt(sqrt(lo*hi))
+  e    = L1/log1p(w[6]^2/rho^2)
+  snap = x -> parse(Float64, string(round(x, sigdigits=13)))   # the closure's literals, not their 1e-16 echoes
+  for (rr, ee) in ((snap(rho), snap(e)), (rho, e))
+    phi = v[1]*rr^(2ee)
+    for ph in (snap(phi), phi)
+      ok(ph .* (rr^2 .+ w.^2).^(-ee)) && return MaternSDF(ph, rr, ee - dim/2, Float64(dim))
+    end
+  end
+  nothing
+end
 
 # mirror of sk_config_args (field order and types must match the header)
 struct SkConfigArgs
@@ -41,6 +97,13 @@ struct SkConfigArgs
   device::Cint
   nufft_width::Cint
   hankel_min_lags::Cint
+  sdf_dparam::Cint
+end
+
+# mirror of sk_stats
+struct SkStats
+  n_unique::Int64; n_outer::Int64; n_panels::Int64; n_accepted::Int64; sum_active::Int64
+  n_steps_launched::Int64; n_syncs::Int64; last_b::Float64
 end
 
 # void (*sk_sdf_batch_fn)(const double* w, double* out, size_t n, void* ctx)
@@ -52,28 +115,45 @@ function _sdf_batch(w::Ptr{Cdouble}, out::Ptr{Cdouble}, n::Csize_t, ctx::Ptr{Cvo
   nothing
 end
 
-mutable struct AdaptiveKernelConfig{S}
+# Fields as in the reference's struct (src/adaptive.jl:2-21; the scratch buffers and rules live behind `handle`).
+mutable struct AdaptiveKernelConfig{S,dS}
   f::S
+  df::dS
+  dim::Int64
+  c::Float64                      # src/adaptive.jl:43-45
+  alpha::Float64
+  p::Float64                      # src/adaptive.jl:42
+  logw::Bool
+  derivative::Bool
+  tol::Float64
+  convergence_criteria::Symbol
+  tail::Union{Float64,Nothing}
+  quadspec::Tuple{Int64,Int64}
+  device::Int
+  sdf::Any                        # what runs on the device: a catalogue SDF, or `f` itself through the callback
   handle::Ptr{Cvoid}
   fref::Tuple{Base.RefValue{Any},Base.RefValue{Any}}  # keeps the closures (f, df) alive for the callbacks
-  dim::Int64; alpha::Float64; tol::Float64; derivative::Bool; logw::Bool
-  convergence_criteria::Symbol; tail::Union{Float64,Nothing}; quadspec::Tuple{Int64,Int64}
 end
 
 _last_error() = unsafe_string(ccall((:sk_last_error, LIB), Cstring, ()))
 _check(code) = (code == 0 || code == 100) ? code : error(_last_error())
 
-_kind(::MaternSDF) = (Cint(1), s -> (s.phi, s.rho, s.nu, s.d, 0.0, 0.0, 0.0, 0.0))
-_kind(::ExponentialSDF) = (Cint(2), s -> (s.a, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
-_kind(::GaussianSDF) = (Cint(3), s -> (s.a, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
-_kind(::Any) = (Cint(0), s -> ntuple(_ -> 0.0, 8))
+_kind(s::MaternSDF)      = (Cint(1), (s.phi, s.rho, s.nu, s.d, 0.0, 0.0, 0.0, 0.0), Cint(s.dparam))
+_kind(s::ExponentialSDF) = (Cint(2), (s.a, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0), Cint(s.dparam))
+_kind(s::GaussianSDF)    = (Cint(3), (s.a, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0), Cint(s.dparam))
+_kind(::Any)             = (Cint(0), ntuple(_ -> 0.0, 8), Cint(0))
 
 function AdaptiveKernelConfig(f; df=nothing, dim=1, alpha=0.0, tol::Float64=1e-8, derivative=false,
                               logw=false, convergence_criteria::Symbol=:both, tail=nothing,
-                              quadspec::Tuple{Int64,Int64}=(2^12, 2^4), device=-1)
+                              quadspec::Tuple{Int64,Int64}=(2^12, 2^4), device=-1, sdf::Symbol=:auto)
   convergence_criteria in (:panel, :tails, :both) ||
     error("Argument convergence_criteria must be one of :panel, :tails, :both.")
-  (kind, prm) = _kind(f)
+  onsdf = f
+  if !(f isa Union{MaternSDF,ExponentialSDF,GaussianSDF}) && sdf == :auto
+    rec = recognize_sdf(f, dim)
+    isnothing(rec) || (onsdf = rec)
+  end
+  (kind, prm, dparam) = _kind(onsdf)
   fref = Ref{Any}(f)
   cb   = kind == 0 ? @cfunction(_sdf_batch, Cvoid, (Ptr{Cdouble}, Ptr{Cdouble}, Csize_t, Ptr{Cvoid})) : C_NULL
   ctx  = kind == 0 ? pointer_from_objref(fref) : C_NULL
@@ -82,20 +162,31 @@ function AdaptiveKernelConfig(f; df=nothing, dim=1, alpha=0.0, tol::Float64=1e-8
   dcb   = (kind == 0 && !isnothing(df)) ? cb : C_NULL
   dctx  = (kind == 0 && !isnothing(df)) ? pointer_from_objref(dfref) : C_NULL
   crit = convergence_criteria == :both ? 0 : convergence_criteria == :panel ? 1 : 2
-  args = SkConfigArgs(kind, prm(f), cb, ctx, dcb, dctx, dim, alpha, tol, derivative, logw, crit,
+  args = SkConfigArgs(kind, prm, cb, ctx, dcb, dctx, dim, alpha, tol, derivative, logw, crit,
                       isnothing(tail) ? 0 : 1, isnothing(tail) ? 0.0 : Float64(tail),
-                      quadspec[1], quadspec[2], device, 0, 0)
+                      quadspec[1], quadspec[2], device, 0, 0, dparam)
   h = Ref{Ptr{Cvoid}}(C_NULL)
   code = _check(ccall((:sk_config_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{SkConfigArgs}), h, args))
   code == 100 && @warn(_last_error())                       # src/adaptive.jl:38
-  m = Ref{Int64}(0); k = Ref{Int64}(0)
-  ccall((:sk_config_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Int64}, Ref{Int64}, Ptr{Cint}),
-        h[], C_NULL, C_NULL, m, k, C_NULL)
-  cfg = AdaptiveKernelConfig(f, h[], (fref, dfref), Int64(dim), Float64(alpha), tol, Bool(derivative), Bool(logw),
-                             convergence_criteria, isnothing(tail) ? nothing : Float64(tail), (m[], k[]))
+  m = Ref{Int64}(0); k = Ref{Int64}(0); p = Ref{Cdouble}(0.0); c = Ref{Cdouble}(0.0)
+  ccall((:sk_config_info, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}, Ref{Int64}, Ref{Int64}, Ptr{Cint}),
+        h[], p, c, m, k, C_NULL)
+  cfg = AdaptiveKernelConfig(f, df, Int64(dim), c[], Float64(alpha), p[], Bool(logw), Bool(derivative), tol,
+                             convergence_criteria, isnothing(tail) ? nothing : Float64(tail), (m[], k[]), Int(device),
+                             onsdf, h[], (fref, dfref))
   finalizer(c -> ccall((:sk_config_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.handle), cfg)
   cfg
 end
+
+# src/adaptive.jl:61-66
+gen_derivative_config(cfg::AdaptiveKernelConfig) =
+  AdaptiveKernelConfig(cfg.f; df=cfg.df, derivative=true, dim=cfg.dim, alpha=cfg.alpha, tol=cfg.tol, logw=cfg.logw,
+                       tail=cfg.tail, convergence_criteria=cfg.convergence_criteria, quadspec=cfg.quadspec,
+                       device=cfg.device)
+
+# src/adaptive.jl:69-72 (quadspec, criteria, tail, logw, derivative fall back to their defaults, as there)
+gen_new_sdf_config(cfg::AdaptiveKernelConfig, new_f, alpha=cfg.alpha) =
+  AdaptiveKernelConfig(new_f; df=cfg.df, dim=cfg.dim, alpha=alpha, tol=cfg.tol, device=cfg.device)
 
 function compute_k0(cfg::AdaptiveKernelConfig)
   k0 = Ref{Cdouble}(0.0)
@@ -103,43 +194,97 @@ function compute_k0(cfg::AdaptiveKernelConfig)
   k0[]
 end
 
-function kernel_values(cfg::AdaptiveKernelConfig, xs::AbstractVector{Float64};
-                       k0=nothing, param_derivative=false, verbose=false)
-  x    = Vector{Float64}(xs)
-  vals = Vector{Float64}(undef, length(x))
-  errs = Vector{Float64}(undef, length(x))
+# the panel schedule of the last call, printed like print_panel_info / print_panel_convergence (src/utils.jl:12-26)
+function _print_trace(cfg::AdaptiveKernelConfig, n::Integer)
+  st = Ref(SkStats(0, 0, 0, 0, 0, 0, 0, 0.0))
+  ccall((:sk_last_stats, LIB), Cint, (Ptr{Cvoid}, Ref{SkStats}), cfg.handle, st)
+  println("Reducing $(n) to $(st[].n_unique) unique lags for evaluation...")   # src/adaptive.jl:100
+  rec = Matrix{Float64}(undef, 5, 4096); len = Ref{Csize_t}(0)
+  ccall((:sk_last_trace, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Ref{Csize_t}), cfg.handle, rec, 4096, len)
+  for j in 1:Int(len[])
+    (a, b, maxerr, nact, acc) = rec[:, j]
+    println("\tsubpanel w in [$(a), $(b)] ", acc != 0 ? "converged" : "did not converge",
+            " with max error $(maxerr) ($(Int(nact)) lags)")
+  end
+end
+
+"""
+    pinned_vector(n)
+
+A `Vector{Float64}` in pinned host memory (sk_host_alloc): kernel_values! copies such arrays by DMA directly, without
+the staging pass that pageable arrays need.  Freed by `finalize` / GC.
+"""
+function pinned_vector(n::Integer)
+  p = Ref{Ptr{Cvoid}}(C_NULL)
+  _check(ccall((:sk_host_alloc, LIB), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, 8*max(n, 1)))
+  v = unsafe_wrap(Vector{Float64}, Ptr{Float64}(p[]), n; own=false)
+  finalizer(_ -> ccall((:sk_host_free, LIB), Cint, (Ptr{Cvoid},), p[]), v)
+  v
+end
+
+"kernel_values into caller-provided vectors (no allocation; no staging copies when they are `pinned_vector`s)."
+function kernel_values!(vals::Vector{Float64}, errs::Vector{Float64}, cfg::AdaptiveKernelConfig, x::Vector{Float64};
+                        k0=nothing, param_derivative=false, verbose=false)
+  (length(vals) == length(x) == length(errs)) || error("kernel_values!: length mismatch")
   GC.@preserve cfg begin
     _check(ccall((:sk_kernel_values, LIB), Cint,
                  (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Cdouble, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
                  cfg.handle, x, length(x), isnothing(k0) ? 0.0 : Float64(k0), isnothing(k0) ? 0 : 1,
                  param_derivative ? 1 : 0, vals, errs))
   end
+  verbose && _print_trace(cfg, length(x))
   (vals, errs)
 end
 
-# Several configs at one lag set -- kernel_sdf_derivatives / kernel_warping_gradients /
-# kernel_singularity_derivative (src/derivatives.jl:51-81) in one call: one upload, one device sort + dedup.
-# Returns a length(cfgs) x length(xs) matrix of values and one of error estimates.
-function kernel_values_multi(cfgs::AbstractVector{<:AdaptiveKernelConfig}, xs::AbstractVector{Float64};
-                             k0s, param_derivative=fill(false, length(cfgs)))
+# src/adaptive.jl:95-108
+function kernel_values(cfg::AdaptiveKernelConfig, xs::AbstractVector{Float64};
+                       k0=nothing, param_derivative=false, verbose=false)
+  x = xs isa Vector{Float64} ? xs : Vector{Float64}(xs)
+  kernel_values!(Vector{Float64}(undef, length(x)), Vector{Float64}(undef, length(x)), cfg, x;
+                 k0=k0, param_derivative=param_derivative, verbose=verbose)
+end
+
+function _multi(sym, cfgs, xs, k0arg, param_derivative)
   x    = Vector{Float64}(xs)
   nc   = length(cfgs)
   hs   = Ptr{Cvoid}[c.handle for c in cfgs]
-  ks   = Float64[k for k in (k0s isa Number ? fill(Float64(k0s), nc) : k0s)]
   pd   = Cint[p ? 1 : 0 for p in param_derivative]
   vals = Matrix{Float64}(undef, length(x), nc)                  # column c = config c (row-major nc x n on the C side)
   errs = Matrix{Float64}(undef, length(x), nc)
   GC.@preserve cfgs begin
-    _check(ccall((:sk_kernel_values_multi, LIB), Cint,
-                 (Ptr{Ptr{Cvoid}}, Csize_t, Ptr{Cdouble}, Csize_t, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}),
-                 hs, nc, x, length(x), ks, pd, vals, errs))
+    if sym == :multi
+      _check(ccall((:sk_kernel_values_multi, LIB), Cint,
+                   (Ptr{Ptr{Cvoid}}, Csize_t, Ptr{Cdouble}, Csize_t, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}),
+                   hs, nc, x, length(x), k0arg, pd, vals, errs))
+    else
+      _check(ccall((:sk_kernel_values_joint, LIB), Cint,
+                   (Ptr{Ptr{Cvoid}}, Csize_t, Ptr{Cdouble}, Csize_t, Cdouble, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}),
+                   hs, nc, x, length(x), k0arg, pd, vals, errs))
+    end
   end
   (permutedims(vals), permutedims(errs))
 end
 
+# Several configs at one lag set -- kernel_sdf_derivatives / kernel_warping_gradients /
+# kernel_singularity_derivative (src/derivatives.jl:51-81) in one call: one upload, one device sort + dedup, then every
+# config's own march.  Returns a length(cfgs) x length(xs) matrix of values and one of error estimates.
+function kernel_values_multi(cfgs::AbstractVector{<:AdaptiveKernelConfig}, xs::AbstractVector{Float64};
+                             k0s, param_derivative=fill(false, length(cfgs)))
+  ks = Float64[k for k in (k0s isa Number ? fill(Float64(k0s), length(cfgs)) : k0s)]
+  _multi(:multi, cfgs, xs, ks, param_derivative)
+end
+
+# The same integrands in ONE joint panel march (shared nodes, spreading and interpolation weights, one batched
+# NUFFT; a panel is accepted / a lag retired when every integrand agrees).  cfgs[1] is the plain kernel, the others
+# differ in the integrand only: `sdf_derivative(S, j)`, `derivative=true`, `logw=true`.  One k0 for all, as
+# gen_kernel_jacobian passes it (src/derivatives.jl:86-99).
+kernel_values_joint(cfgs::AbstractVector{<:AdaptiveKernelConfig}, xs::AbstractVector{Float64}; k0,
+                    param_derivative=fill(false, length(cfgs))) = _multi(:joint, cfgs, xs, Float64(k0), param_derivative)
+
 # Lags of point pairs formed on the device -- what gen_kernel_setup / gen_kernel do with
 # `norm(warp_pts[j] - warp_pts[k])` (src/model.jl:64-65,76).  pts: vector of points (numbers or static vectors),
-# pairs: vector of 1-based index tuples as in sm.kernel_index_pairs.
+# pairs: vector of 1-based index tuples as in sm.kernel_index_pairs.  `Dict(zip(raw_pairs, vals))` is the reference's
+# SpectralKernel lookup table (src/model.jl:76-77).
 function kernel_values_pairs(cfg::AdaptiveKernelConfig, pts::AbstractVector, pairs::AbstractVector{<:Tuple{Integer,Integer}};
                              k0=nothing, param_derivative=false)
   pdim = length(first(pts))
@@ -175,6 +320,40 @@ function build_dense_cov_matrix(cfg::AdaptiveKernelConfig, pts::AbstractVector)
                  cfg.handle, p, length(pts), pdim, out))
   end
   out
+end
+
+# One process, every GPU of the node: a config replica per device, the sorted unique lag set cut into contiguous
+# blocks (sk_sharded_create / sk_kernel_values_sharded).  Same call shape as kernel_values.
+mutable struct ShardedKernelConfig
+  handle::Ptr{Cvoid}
+  base::AdaptiveKernelConfig      # keeps closures alive; only catalogue SDFs may be shared across device threads
+end
+function ShardedKernelConfig(f; devices::AbstractVector{<:Integer}=Int[], kw...)
+  base = AdaptiveKernelConfig(f; kw...)
+  _kind(base.sdf)[1] == 0 && error("ShardedKernelConfig: catalogue (or recognised) SDFs only -- a Julia closure cannot be called from the per-device host threads")
+  (kind, prm, dparam) = _kind(base.sdf)
+  crit = base.convergence_criteria == :both ? 0 : base.convergence_criteria == :panel ? 1 : 2
+  args = SkConfigArgs(kind, prm, C_NULL, C_NULL, C_NULL, C_NULL, base.dim, base.alpha, base.tol, base.derivative,
+                      base.logw, crit, isnothing(base.tail) ? 0 : 1, isnothing(base.tail) ? 0.0 : base.tail,
+                      base.quadspec[1], base.quadspec[2], -1, 0, 0, dparam)
+  nd = Ref{Cint}(0); ccall((:sk_device_count, LIB), Cint, (Ref{Cint},), nd)
+  devs = isempty(devices) ? Cint.(0:nd[]-1) : Cint.(devices)
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  _check(ccall((:sk_sharded_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{SkConfigArgs}, Ptr{Cint}, Cint), h, args, devs, length(devs)))
+  sh = ShardedKernelConfig(h[], base)
+  finalizer(s -> ccall((:sk_sharded_destroy, LIB), Cvoid, (Ptr{Cvoid},), s.handle), sh)
+  sh
+end
+function kernel_values(sh::ShardedKernelConfig, xs::AbstractVector{Float64}; k0=nothing, param_derivative=false)
+  x = Vector{Float64}(xs)
+  vals = Vector{Float64}(undef, length(x)); errs = Vector{Float64}(undef, length(x))
+  GC.@preserve sh begin
+    _check(ccall((:sk_kernel_values_sharded, LIB), Cint,
+                 (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Cdouble, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
+                 sh.handle, x, length(x), isnothing(k0) ? 0.0 : Float64(k0), isnothing(k0) ? 0 : 1,
+                 param_derivative ? 1 : 0, vals, errs))
+  end
+  (vals, errs)
 end
 
 end # module

@@ -153,3 +153,30 @@ def test_c4_dim2_pairwise_1e6(sk, oracle):
     cfg_d = sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, 2), dim=2, tol=tol, hankel_min_lags=-1)
     kd, _ = sk.kernel_values(cfg_d, lags[sub], k0=k0)
     assert np.abs(kd - ks[sub]).max() / k0 <= 1e-11
+
+
+def test_sharded_entry_on_the_visible_devices(sk):
+    # sk_kernel_values_sharded with every visible device (one on the test box): same call shape as kernel_values;
+    # with one shard it IS the single-device call; asking for a device that is not there fails loudly
+    n = 200000
+    rs = 10.0 ** np.linspace(-6, 0, n)
+    nd = sk.device_count()
+    assert nd >= 1
+    sh = sk.ShardedKernelConfig(sk.SDF.matern(1, 1, 1.5), n_devices=nd)
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5))
+    k0 = np.pi / 2
+    v, e = sh.kernel_values(rs, k0=k0)
+    v1, e1 = sk.kernel_values(cfg, rs, k0=k0)
+    info = sh.last()
+    assert info[0]["lo"] == 0 and info[-1]["hi"] == n and all(d["stats"]["n_panels"] >= 1 for d in info)
+    if nd == 1:
+        assert np.array_equal(v, v1) and np.array_equal(e, e1)
+    assert np.abs(v - v1).max() <= 1e-8 * k0
+    rng = np.random.default_rng(4)
+    xs = np.r_[rs[rng.permutation(n)[:5000]], 0.0, rs[:10]]
+    vu, _ = sh.kernel_values(xs)  # K(0) once on the host, shared by the shards
+    truth = k0 * (1 + 2 * np.pi * xs) * np.exp(-2 * np.pi * xs)
+    assert np.abs(vu - truth).max() <= 1e-7 * k0
+    with pytest.raises(sk.SpectralKernelsError) as ex:
+        sk.ShardedKernelConfig(sk.SDF.matern(1, 1, 1.5), devices=[0, nd])
+    assert ex.value.code == 6

@@ -22,7 +22,7 @@ def test_catalogue_parameter_derivatives_on_the_device(sk, oracle):
     k0 = sk.compute_k0(sk.AdaptiveKernelConfig(f, quadspec=(256, 16)))
     for j in range(3):
         dev = sk.AdaptiveKernelConfig(f.d(j), quadspec=(256, 16), tol=1e-10)
-        cb = sk.AdaptiveKernelConfig(lambda w, j=j: f.d(j)(w), quadspec=(256, 16), tol=1e-10)
+        cb = sk.AdaptiveKernelConfig(lambda w, j=j: f.d(j)(w), quadspec=(256, 16), tol=1e-10, sdf="callback")
         kd, ed = sk.kernel_values(dev, rs, k0=k0, param_derivative=True)
         kc, ec = sk.kernel_values(cb, rs, k0=k0, param_derivative=True)
         assert np.abs(kd - kc).max() <= 1e-11 * k0 and dev.last_stats()["n_panels"] == cb.last_stats()["n_panels"]

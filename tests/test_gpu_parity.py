@@ -178,16 +178,40 @@ def test_derivative_and_param_derivative(sk, oracle):
 def test_callback_sdf_equals_catalogue(sk, oracle):
     rs = 10.0 ** np.linspace(-5, 0, 150)
     cat = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5), quadspec=(256, 16))
-    cb = sk.AdaptiveKernelConfig(lambda w: (1.0 + w * w) ** -2.0, quadspec=(256, 16))
+    cb = sk.AdaptiveKernelConfig(lambda w: (1.0 + w * w) ** -2.0, quadspec=(256, 16), sdf="callback")
     a, ea = sk.kernel_values(cat, rs, k0=np.pi / 2)
     b, eb = sk.kernel_values(cb, rs)  # k0 through the batched closure
     assert np.abs(a - b).max() <= 1e-11 and np.abs(ea - eb).max() <= 1e-11
     assert cb.last_stats()["n_panels"] == cat.last_stats()["n_panels"]
     # scalar-only Python closures work too
     import math
-    cb2 = sk.AdaptiveKernelConfig(lambda w: math.exp(-abs(float(w))), quadspec=(64, 4))
+    cb2 = sk.AdaptiveKernelConfig(lambda w: math.exp(-abs(float(w))), quadspec=(64, 4), sdf="callback")
     c, _ = sk.kernel_values(cb2, np.array([0.0, 0.1, 1.0]))
     assert np.abs(c - oracle.exponential_cov(np.array([0.0, 0.1, 1.0]))).max() <= 1e-7
+
+
+def test_closure_recognition_and_config_helpers(sk, oracle):
+    # README-style closures (README.md:26) are recognised as catalogue entries and evaluated on the device: same
+    # results as the explicit catalogue config, no host callback per panel; anything else stays a callback
+    rs = 10.0 ** np.linspace(-5, 0, 400)
+    auto = sk.AdaptiveKernelConfig(lambda w: (1.0 + w * w) ** -2.0, quadspec=(256, 16))
+    cat = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5), quadspec=(256, 16))
+    assert auto.f.kind == cat.f.kind and auto.f.params == cat.f.params
+    a, _ = sk.kernel_values(auto, rs, k0=np.pi / 2)
+    b, _ = sk.kernel_values(cat, rs, k0=np.pi / 2)
+    assert np.array_equal(a, b) and auto.last_stats()["n_syncs"] == cat.last_stats()["n_syncs"]
+    assert sk.recognize_sdf(lambda w: 1.0 / (1.0 + w ** 4)) is None
+    assert sk.recognize_sdf(lambda w: (1.0 + w * w) ** -2.0 + 1e-9 * np.exp(-w)) is None
+    assert sk.AdaptiveKernelConfig(lambda w: (1.0 + w * w) ** -2.0, quadspec=(64, 4), sdf="callback").f.kind == 0
+    # gen_derivative_config / gen_new_sdf_config (src/adaptive.jl:61-72)
+    base = sk.AdaptiveKernelConfig(sk.SDF.matern(2.14, 0.97, 0.89), alpha=0.5, tol=1e-6, quadspec=(256, 16), tail=-2.0,
+                                   convergence_criteria="tails")
+    d = sk.gen_derivative_config(base)
+    assert d.derivative and d.alpha == 0.5 and d.tol == 1e-6 and d.quadspec == (256, 16) and d.tail == -2.0
+    assert d.convergence_criteria == "tails" and d.p == base.p + 1 and d.c == base.c * (-2 * np.pi)
+    g = sk.gen_new_sdf_config(base, sk.SDF.exponential(1.0))
+    assert g.alpha == 0.5 and g.tol == 1e-6 and g.quadspec == (4096, 16) and g.tail is None  # defaults restored (:69-72)
+    assert sk.gen_new_sdf_config(base, sk.SDF.exponential(1.0), alpha=0.0).alpha == 0.0
 
 
 def test_quadspec_warning_and_errors(sk):
@@ -201,7 +225,7 @@ def test_quadspec_warning_and_errors(sk):
         sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5, 4), dim=4, alpha=0.5, logw=True)
     assert e.value.code == 7 and "d > 2" in str(e.value)
     with pytest.raises(sk.SpectralKernelsError) as e:  # src/quadrature.jl:194 needs df
-        sk.AdaptiveKernelConfig(lambda w: np.exp(-w), alpha=0.5, logw=True)
+        sk.AdaptiveKernelConfig(lambda w: np.exp(-w), alpha=0.5, logw=True, sdf="callback")
     assert e.value.code == 1
     # NaN SDF: int1 and int2 are both NaN -> never accepted -> bisected down to b-a < 1e-16
     # (src/quadrature.jl:165 precedence quirk, src/utils.jl:28-36)
@@ -329,7 +353,7 @@ def test_logw_callback_sdf_with_df(sk, oracle):
     rs = np.linspace(0.01, 1.1, 500)
     kw = dict(dim=1, alpha=0.5, tol=1e-8, logw=True)
     k0 = sk.compute_k0(sk.AdaptiveKernelConfig(sk.SDF.matern(*LW_PARMS, 1), dim=1, alpha=0.5))
-    a, ea = sk.kernel_values(sk.AdaptiveKernelConfig(f, df=df, **kw), rs, k0=k0, param_derivative=True)
+    a, ea = sk.kernel_values(sk.AdaptiveKernelConfig(f, df=df, sdf="callback", **kw), rs, k0=k0, param_derivative=True)
     b, eb = sk.kernel_values(sk.AdaptiveKernelConfig(sk.SDF.matern(*LW_PARMS, 1), **kw), rs, k0=k0, param_derivative=True)
     assert np.abs(a - b).max() / abs(k0) <= 1e-12
     ocfg = oracle.AdaptiveKernelConfig(f, df=df, **kw)
