@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="lags in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend at N > 1: nccl (= RCCL over xGMI; the driver's runs) or gloo "
+                         "(rehearsal of the multi-rank plumbing with the ranks sharing the visible GPUs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -134,8 +137,12 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+            local_rank = local_rank % max(1, torch.cuda.device_count())
 
     import spectralkernels_jl_amd as sk
     from spectralkernels_jl_amd import dist as skdist
@@ -152,7 +159,7 @@ def main():
     if args.workload == "C3":
         k0 = 1.0  # normalised by the closed form; the reference's own QuadGK call fails on this SDF (demo TODO)
     else:
-        k0 = skdist.shared_k0(cfg, dist, torch.device("cuda", local_rank) if torch else None)
+        k0 = skdist.shared_k0(cfg, dist, torch.device("cuda", local_rank) if (torch and args.backend == "nccl") else None)
 
     rs = shard_grid(w, rank, world, args.shard)
     n = rs.size
@@ -174,7 +181,7 @@ def main():
     st = cfg.last_stats()
     if dist is not None:
         t = torch.tensor([dt_local, float(st["n_panels"]), float(st["n_outer"]), float(n), float(st["sum_active"])],
-                         dtype=torch.float64, device="cuda")
+                         dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         rows = [x.cpu().numpy() for x in allt]
@@ -209,9 +216,9 @@ def main():
 
         def leg(name, xs, into=None):
             out = {}
-            if into is None:
+            if into is None:  # fresh result arrays every call, as the reference's kernel_values returns them
                 fn = lambda: out.__setitem__("r", sk.kernel_values(cfg, xs, k0=k0))
-            else:  # caller-provided (pinned) result arrays
+            else:             # caller-provided result arrays (the C ABI's contract), reused across calls
                 fn = lambda: out.__setitem__("r", sk.kernel_values_into(cfg, xs, k0, into[0], into[1]))
             dth = timed(fn, hsteps, hwarm, nofence) / hsteps
             tm = sk.host_timing(cfg)
@@ -219,18 +226,21 @@ def main():
                           "split_ms": {k: round(v, 4) for k, v in tm.items()}, "unique_lags": cfg.last_stats()["n_unique"]}
             return out["r"]
 
-        hv, _ = leg("sorted", rs)
+        hv, _ = leg("sorted", rs, into=(np.empty(n), np.empty(n)))
         host_err = float(np.abs(hv - ks).max() / abs(k0))
+        leg("sorted_fresh_result_arrays", rs)
         prng = np.random.default_rng(7)
         perm = prng.permutation(n)
         xs_p = np.ascontiguousarray(np.r_[rs[perm[: n - n // 10]], rs[perm[: n // 10]]])  # 10 % duplicates, shuffled
         prng.shuffle(xs_p)
-        pv, _ = leg("permuted_with_duplicates", xs_p)
+        pv, _ = leg("permuted_with_duplicates", xs_p, into=(np.empty(n), np.empty(n)))
         truth_p = k0 * (1 + 2 * np.pi * xs_p) * np.exp(-2 * np.pi * xs_p) if args.workload == "C2" else None
         px, pk, pe = sk.pinned_empty(n), sk.pinned_empty(n), sk.pinned_empty(n)
         px[:] = rs
         leg("sorted_pinned_arrays", px, into=(pk, pe))
-        host = {"what": "sk_kernel_values: host array in, two host arrays out (src/adaptive.jl:95-108), %d steps" % hsteps,
+        host = {"what": "sk_kernel_values: pageable host array in, two pageable host arrays out (src/adaptive.jl:95-108), "
+                        "%d steps; legs: result arrays reused / fresh per call / permuted input with duplicates / "
+                        "all three arrays in pinned memory (sk_host_alloc)" % hsteps,
                 "ms_per_step": legs["sorted"]["ms_per_step"], "value": legs["sorted"]["value"], "unit": "r-targets/s",
                 "GB/s_effective": legs["sorted"]["GB/s_effective"], "legs": legs,
                 "max_abs_diff_vs_device_leg_over_k0": host_err,
@@ -379,7 +389,7 @@ def main():
                "max_rel_err_vs_closed_form": max_rel_err,
                "panels": {"outer": st["n_outer"], "nufft_pairs": st["n_panels"], "abar": abar,
                           "steps_launched": st["n_steps_launched"], "host_syncs": st["n_syncs"]},
-               "rccl_ranks": world if dist is not None else 0, "per_rank": per_rank,
+               "rccl_ranks": world if (dist is not None and args.backend == "nccl") else 0, "per_rank": per_rank,
                "host_to_host": host, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if dist is not None:

@@ -164,6 +164,19 @@ int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs
 int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, double k0,
                            const int* param_derivative, double* vals_out, double* errs_out);
 
+/* gen_kernel + gen_kernel_jacobian for point pairs on the device (src/model.jl:53-77, src/derivatives.jl:86-112):
+ * the lags norm(pts[j] - pts[k]) of the pairs are formed on the device (pts: the WARPED points, npts x pdim row-major;
+ * pairs: npairs x 2 zero-based), ONE joint march evaluates every integrand, and the Jacobian is assembled on the
+ * device.  role[t] of cfgs[t]: 0 = the kernel itself (cfgs[0]; vals_out, npairs values in pair order -- the values of
+ * the reference's lookup table Dict(raw_pairs => values)); 1 = Jacobian column col[t] takes this integrand
+ * (SDF-parameter derivatives, the logw integrand; evaluated with param_derivative = true as at :68,80); 2 = K'
+ * (derivative = true): column warp_cols[q] takes K'(lag_e) * dlag[e * nwarp + q], dlag = d lag_e / d warp-parameter q
+ * from the caller's differentiation of the warp (:46-54).  jac_out: npairs x ncols row-major; columns nobody claims
+ * are zero.  Config requirements as for sk_kernel_values_joint. */
+int sk_kernel_jacobian_pairs(sk_config* const* cfgs, size_t ncfg, const int* role, const int* col, const double* pts,
+                             size_t npts, int pdim, const int64_t* pairs, size_t npairs, double k0, const double* dlag,
+                             int nwarp, const int* warp_cols, int ncols, double* vals_out, double* jac_out);
+
 /* One process, several GPUs (the reference's kernel_values is one call on one host Vector,
  * src/adaptive.jl:95-98): the sorted unique lag set is cut into contiguous blocks, one per device; every device
  * holds a replica of the config and marches its own block (its panel widths follow its own largest lag,

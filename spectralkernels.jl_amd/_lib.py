@@ -61,6 +61,8 @@ def load():
     L.sk_kernel_values_device.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_int, vp, vp, vp]
     L.sk_kernel_values_multi.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp]
     L.sk_kernel_values_joint.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_double, vp, vp, vp]
+    L.sk_kernel_jacobian_pairs.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_double, vp,
+                                           C.c_int, vp, C.c_int, vp, vp]
     L.sk_kernel_values_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp]
     L.sk_kernel_values_pairs_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_double, C.c_int, vp, vp, vp]
     L.sk_dense_cov_matrix.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]

@@ -273,7 +273,7 @@ def kernel_values(config, xs, k0=None, param_derivative=False, verbose=False):
     src/adaptive.jl:95-108.  xs: host array (any order, duplicates allowed)."""
     xs = np.ascontiguousarray(xs, dtype=np.float64)
     n = xs.size
-    vals, errs = np.zeros(n), np.zeros(n)
+    vals, errs = np.empty(n), np.empty(n)
     _check(L.load().sk_kernel_values(config._h, xs.ctypes.data_as(C.c_void_p), n, 0.0 if k0 is None else float(k0),
                                      0 if k0 is None else 1, int(bool(param_derivative)),
                                      vals.ctypes.data_as(C.c_void_p), errs.ctypes.data_as(C.c_void_p)))
@@ -335,6 +335,30 @@ def kernel_values_joint(configs, xs, k0, param_derivative=False):
                                            pds.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
                                            errs.ctypes.data_as(C.c_void_p)))
     return vals, errs
+
+
+def kernel_jacobian_pairs(configs, roles, cols, pts, pairs, k0, dlag=None, warp_cols=(), ncols=None):
+    """gen_kernel + gen_kernel_jacobian for point pairs on the device (sk_kernel_jacobian_pairs; src/model.jl:53-77,
+    src/derivatives.jl:86-112).  configs[0]: the kernel (role 0); role 1: Jacobian column cols[t] = this integrand;
+    role 2: K' (derivative=True), spread over `warp_cols` through dlag[e, q] = d lag_e / d warp-parameter q.
+    pts: warped points; pairs: zero-based index pairs.  Returns (values in pair order, Jacobian npairs x ncols)."""
+    pts = _points(pts)
+    npts, pdim = pts.shape
+    pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+    npairs, nc = pairs.shape[0], len(configs)
+    roles = np.ascontiguousarray(roles, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    wc = np.ascontiguousarray(warp_cols, dtype=np.int32)
+    nwarp = wc.size
+    if ncols is None:
+        ncols = int(max([c for c, r in zip(cols, roles) if r == 1] + list(wc) + [-1])) + 1
+    dl = np.ascontiguousarray(dlag, dtype=np.float64).reshape(npairs, nwarp) if nwarp else None
+    handles = (C.c_void_p * nc)(*[c._h for c in configs])
+    vals, jac = np.empty(npairs), np.empty((npairs, max(ncols, 1)))
+    p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    _check(L.load().sk_kernel_jacobian_pairs(handles, nc, p(roles), p(cols), p(pts), npts, pdim, p(pairs), npairs, float(k0),
+                                             p(dl), nwarp, p(wc) if nwarp else None, int(ncols), p(vals), p(jac)))
+    return vals, jac[:, :ncols]
 
 
 def _points(pts):

@@ -230,6 +230,9 @@ void launch_joint_spread(const DevConst& dc, const EsConst* ec, const DevBuffers
 void launch_joint_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const JointSpec& js, const JointBufs& jb,
                          int slot, long long n, hipStream_t st);
 
+void launch_jac_assemble(const double* vals, long long n, int ncfg, const int* map, const double* dlag, int nwarp, int t_warp,
+                         int ncols, double* jac, hipStream_t st);
+
 // seam kernels for sk_panel_sums
 void launch_seam_spread(const DevConst& dc, const double* nodes, const double* coef, int64_t M, double Cx, double X,
                         double kappa, double2* fft, hipStream_t st);

@@ -3,7 +3,10 @@
 // Counterpart of the call pattern of src/derivatives.jl:51-112 (gen_kernel_jacobian): kernel_sdf_derivatives (one
 // kernel_values per dS/dtheta_j), kernel_warping_gradients (derivative=true), kernel_singularity_derivative
 // (logw=true), all on the same warp_lags with the same k0.
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "sk_config.h"
 
@@ -27,8 +30,13 @@ size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
 
-extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, double k0,
-                                      const int* param_derivative, double* vals_out, double* errs_out) {
+namespace {
+
+// The joint march behind both entries.  Lags: a host array `xs` (staged upload) or, if xs == nullptr, `d_lags_in`
+// already on the device (any order).  On return *d_vals / *d_errs point at nt x n device arrays in INPUT order
+// (row t = integrand t), valid until the next joint call on cfgs[0].
+int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const double* d_lags_in, size_t n, double k0,
+               const int* param_derivative, double** d_vals, double** d_errs, size_t extra_bytes, void** extra) {
   if (!cfgs || ncfg == 0 || !cfgs[0]) return fail(SK_EINVAL, "null config");
   if (ncfg > (size_t)kJointMax) return fail(SK_EINVAL, "at most 8 integrands per joint march");
   sk_config* c0 = cfgs[0];
@@ -68,6 +76,7 @@ extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const
   HIPCHK(hipSetDevice(c0->device));
   hipStream_t st = c0->own_stream;
   const int nt = js.nt, ntr = js.ntr;
+  const size_t extra_b = a256(extra_bytes);
   const int64_t n1 = c0->dc.n1;
   // ---- values at x == 0 (src/adaptive.jl:134-145)
   JointBufs jb;
@@ -85,23 +94,32 @@ extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const
   const size_t a8 = a256(n * 8);
   const size_t tb = sort_unique_temp_bytes((long long)n);
   const size_t fft_b = a256((size_t)ntr * 4 * n1 * sizeof(double2));
-  const size_t need = 3 * a8 + tb + 512 + (size_t)(8 * nt + 2) * a8 + 2 * fft_b;
+  const size_t need = 3 * a8 + tb + 512 + (size_t)(8 * nt) * a8 + (size_t)(2 * nt) * a8 + 2 * fft_b + extra_b;
   int rc = ensure_dev_buf(&c0->d_joint, &c0->joint_bytes, need);
   if (rc) return rc;
   char* p = (char*)c0->d_joint;
+  if (extra) *extra = p;
+  p += extra_b;
   double* d_xs = (double*)p; p += a8;
   double* uxs = (double*)p; p += a8;
   long long* inv = (long long*)p; p += a8;
   long long* d_nu = (long long*)p; p += 256;
   void* tmp = p; p += a256(tb) + 256;
-  double* big = (double*)p; p += (size_t)(8 * nt + 2) * a8;
+  double* big = (double*)p; p += (size_t)(8 * nt) * a8;
+  double* gath = (double*)p; p += (size_t)(2 * nt) * a8;  // results in input order: nt x n values, then nt x n errors
   jb.fft = (double2*)p; p += fft_b;
   jb.fft_out = (double2*)p;
   // ---- lags: staged upload, one sort + dedup for all integrands (src/adaptive.jl:99-120)
-  int order = SK_ORDER_UNKNOWN;
-  rc = h2d_doubles(c0, d_xs, xs, n, st, &order);
-  if (rc) return rc;
+  int order = SK_ORDER_UNSORTED;  // device lags (pairwise distances): sorted and deduplicated below
+  if (xs) {
+    rc = h2d_doubles(c0, d_xs, xs, n, st, &order);
+    if (rc) return rc;
+  } else {
+    d_xs = const_cast<double*>(d_lags_in);
+    launch_check_sorted(d_xs, (long long)n, c0->db.flags, st);  // invalid pairs surface as NaN lags (k_pair_lags)
+  }
   if (order == SK_ORDER_INVALID) return fail(SK_EINVAL, "lags must be non-negative and finite");
+  if (order == SK_ORDER_UNKNOWN) order = SK_ORDER_UNSORTED;  // pinned host input of unknown order: sorting is harmless
   long long nu = (long long)n;
   const bool sorted = (order == SK_ORDER_SORTED);
   const double* lags = d_xs;
@@ -119,7 +137,6 @@ extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const
   jb.accE[0] = q; q += (size_t)nt * sn; jb.accE[1] = q; q += (size_t)nt * sn;
   jb.P[0] = q; q += (size_t)nt * sn; jb.P[1] = q; q += (size_t)nt * sn;
   jb.ks = q; q += (size_t)nt * sn; jb.errs = q; q += (size_t)nt * sn;
-  double* gk = q;  // gathered values, then n doubles later the gathered error estimates (unsorted input)
   // ---- rocFFT plan for this number of transforms
   if (!c0->plan_joint[ntr]) {
     size_t len[1] = {(size_t)n1};
@@ -142,7 +159,6 @@ extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const
   db.ks = jb.ks;
   db.errs = jb.errs;
   db.check_input = 0;
-  if (order == SK_ORDER_UNKNOWN) launch_check_sorted(lags, nu, db.flags, st);  // pinned input: not looked at yet
   std::memset(&c0->stats, 0, sizeof(c0->stats));
   c0->stats.n_unique = nu;
   const DevState* hs = &c0->h_status->state;
@@ -165,11 +181,10 @@ extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const
     launch_advance(dcj, db, mode, t, nu, k0, jb.ks0[0], seq, st);
     rc = joint_wait_status(c0, seq, st);
     if (rc) return rc;
-    if (order == SK_ORDER_UNKNOWN && (c0->h_status->flags[0] || c0->h_status->flags[1])) {
+    if (!xs && (c0->h_status->flags[1] & 1)) {  // device lags: the validity check ran on the unsorted input
       HIPCHK(hipStreamSynchronize(st));
       HIPCHK(hipMemsetAsync(c0->db.flags, 0, 2 * sizeof(int), st));
-      return fail(SK_EINVAL, c0->h_status->flags[1] ? "lags must be non-negative and finite"
-                                                    : "joint march on pinned input needs strictly increasing lags");
+      return fail(SK_EINVAL, "lags must be non-negative and finite (index pair out of range?)");
     }
     if (hs->done) break;
     mode = SK_MODE_ASIS;
@@ -197,16 +212,121 @@ extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const
       HIPCHK(hipMemcpyAsync(jb.errs + (size_t)tt * sn, &c0->h_scal[2 * tt + 1], sizeof(double), hipMemcpyHostToDevice, st));
     }
   }
-  // ---- results back, integrand by integrand
-  for (int tt = 0; tt < nt; ++tt) {
-    if (sorted) {
-      rc = d2h_doubles(c0, vals_out + (size_t)tt * n, jb.ks + (size_t)tt * sn, n, st);
-      if (!rc) rc = d2h_doubles(c0, errs_out + (size_t)tt * n, jb.errs + (size_t)tt * sn, n, st);
-    } else {
-      launch_gather(jb.ks + (size_t)tt * sn, jb.errs + (size_t)tt * sn, inv, (long long)n, gk, gk + n, st);
-      rc = d2h_doubles2(c0, vals_out + (size_t)tt * n, errs_out + (size_t)tt * n, gk, n, st);
-    }
-    if (rc) return rc;
+  // ---- results in input order on the device (sorted input: they already are)
+  if (!xs && c0->h_status->flags[0]) HIPCHK(hipMemsetAsync(c0->db.flags, 0, 2 * sizeof(int), st));  // "unsorted" is expected
+  if (sorted) {
+    *d_vals = jb.ks;
+    *d_errs = jb.errs;
+  } else {
+    for (int tt = 0; tt < nt; ++tt)
+      launch_gather(jb.ks + (size_t)tt * sn, jb.errs + (size_t)tt * sn, inv, (long long)n, gath + (size_t)tt * n,
+                    gath + (size_t)(nt + tt) * n, st);
+    *d_vals = gath;
+    *d_errs = gath + (size_t)nt * n;
   }
   return SK_OK;
 }
+
+}  // namespace
+
+extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, double k0,
+                                      const int* param_derivative, double* vals_out, double* errs_out) {
+  if (!xs && n) return fail(SK_EINVAL, "null lags");
+  static const bool timing = getenv("SK_JOINT_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  double *dv = nullptr, *de = nullptr;
+  int rc = joint_core(cfgs, ncfg, xs, nullptr, n, k0, param_derivative, &dv, &de, 0, nullptr);
+  if (rc || n == 0) return rc;
+  const auto t1 = std::chrono::steady_clock::now();
+  sk_config* c0 = cfgs[0];
+  for (size_t t = 0; t < ncfg; ++t) {
+    rc = d2h_doubles(c0, vals_out + t * n, dv + t * n, n, c0->own_stream);
+    if (!rc) rc = d2h_doubles(c0, errs_out + t * n, de + t * n, n, c0->own_stream);
+    if (rc) return rc;
+  }
+  if (timing)
+    fprintf(stderr, "[sk joint] upload + march %.3f ms, download %.3f ms\n",
+            std::chrono::duration<double, std::milli>(t1 - t0).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+  return SK_OK;
+}
+
+// gen_kernel + gen_kernel_jacobian for point pairs (src/model.jl:53-77, src/derivatives.jl:86-112): see the header.
+extern "C" int sk_kernel_jacobian_pairs(sk_config* const* cfgs, size_t ncfg, const int* role, const int* col, const double* pts,
+                                        size_t npts, int pdim, const int64_t* pairs, size_t npairs, double k0,
+                                        const double* dlag, int nwarp, const int* warp_cols, int ncols, double* vals_out,
+                                        double* jac_out) {
+  if (!cfgs || ncfg == 0 || !cfgs[0] || !role || !col || !pts || !pairs) return fail(SK_EINVAL, "null argument");
+  if (pdim < 1 || npts < 1 || ncols < 0 || nwarp < 0 || (nwarp && (!dlag || !warp_cols))) return fail(SK_EINVAL, "bad argument");
+  if (npairs == 0) return SK_OK;
+  sk_config* c0 = cfgs[0];
+  HIPCHK(hipSetDevice(c0->device));
+  hipStream_t st = c0->own_stream;
+  std::vector<int> pd(ncfg, 0);
+  int t_warp = -1;
+  for (size_t t = 0; t < ncfg; ++t) {
+    if (role[t] == 1) {
+      if (col[t] < 0 || col[t] >= ncols) return fail(SK_EINVAL, "Jacobian column out of range");
+      pd[t] = 1;  // kernel_sdf_derivatives / kernel_singularity_derivative pass param_derivative=true (:68,80)
+    } else if (role[t] == 2) {
+      t_warp = (int)t;
+    } else if (role[t] != 0) {
+      return fail(SK_EINVAL, "role must be 0 (K), 1 (a Jacobian column) or 2 (K' for the warping columns)");
+    }
+  }
+  if (nwarp && t_warp < 0) return fail(SK_EINVAL, "warping columns need a config with role 2 (derivative=true)");
+  for (int q = 0; q < nwarp; ++q)
+    if (warp_cols[q] < 0 || warp_cols[q] >= ncols) return fail(SK_EINVAL, "Jacobian column out of range");
+  // scratch ahead of the march's buffers: points, pairs, lags, d lag / d warp, the Jacobian, column maps
+  const size_t b_pts = a256(npts * pdim * 8), b_pairs = a256(2 * npairs * 8), b_lags = a256(npairs * 8),
+               b_dlag = a256((size_t)npairs * (nwarp > 0 ? nwarp : 1) * 8), b_jac = a256((size_t)npairs * (ncols > 0 ? ncols : 1) * 8),
+               b_map = a256((ncfg * 2 + (size_t)nwarp + 8) * sizeof(int));
+  // the lags must exist before the march: a first (cheap) pass sizes the buffers with n = npairs
+  void* extra = nullptr;
+  {
+    // allocate by running the size computation of joint_core on an empty call is not possible; reserve directly
+    const size_t a8 = a256(npairs * 8);
+    const size_t tb = sort_unique_temp_bytes((long long)npairs);
+    JointSpec dummy;  // only ntr matters for sizing: at most two transforms per integrand
+    (void)dummy;
+    const size_t fft_b = a256((size_t)(2 * ncfg) * 4 * c0->dc.n1 * sizeof(double2));
+    const size_t need = 3 * a8 + tb + 512 + (size_t)(10 * ncfg) * a8 + 2 * fft_b + b_pts + b_pairs + b_lags + b_dlag + b_jac + b_map + 4096;
+    int rc0 = ensure_dev_buf(&c0->d_joint, &c0->joint_bytes, need);
+    if (rc0) return rc0;
+  }
+  const size_t extra_bytes = b_pts + b_pairs + b_lags + b_dlag + b_jac + b_map;
+  char* e = (char*)c0->d_joint;  // joint_core places `extra` at the head of the (already large enough) buffer
+  double* d_pts = (double*)e; e += b_pts;
+  int64_t* d_pairs = (int64_t*)e; e += b_pairs;
+  double* d_lags = (double*)e; e += b_lags;
+  double* d_dlag = (double*)e; e += b_dlag;
+  double* d_jac = (double*)e; e += b_jac;
+  int* d_map = (int*)e;
+  int rc = h2d_doubles(c0, d_pts, pts, npts * pdim, st, nullptr);
+  if (!rc) rc = hipStreamSynchronize(st) == hipSuccess ? SK_OK : fail(SK_EHIP, "stream synchronisation failed");
+  if (!rc) rc = h2d_doubles(c0, (double*)d_pairs, (const double*)pairs, 2 * npairs, st, nullptr);
+  if (!rc && nwarp) {
+    if (hipStreamSynchronize(st) != hipSuccess) rc = fail(SK_EHIP, "stream synchronisation failed");
+    if (!rc) rc = h2d_doubles(c0, d_dlag, dlag, npairs * (size_t)nwarp, st, nullptr);
+  }
+  if (rc) return rc;
+  std::vector<int> hmap;
+  for (size_t t = 0; t < ncfg; ++t) { hmap.push_back(role[t]); hmap.push_back(col[t]); }
+  for (int q = 0; q < nwarp; ++q) hmap.push_back(warp_cols[q]);
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipMemcpy(d_map, hmap.data(), hmap.size() * sizeof(int), hipMemcpyHostToDevice));
+  launch_pair_lags(d_pts, (long long)npts, pdim, (const long long*)d_pairs, (long long)npairs, d_lags, st);
+  double *dv = nullptr, *de = nullptr;
+  rc = joint_core(cfgs, ncfg, nullptr, d_lags, npairs, k0, pd.data(), &dv, &de, extra_bytes, &extra);
+  if (rc) return rc;
+  if (extra != (void*)c0->d_joint) return fail(SK_EHIP, "internal error: joint buffers moved");
+  if (ncols > 0) {
+    launch_jac_assemble(dv, (long long)npairs, (int)ncfg, d_map, d_dlag, nwarp, t_warp, ncols, d_jac, st);
+    rc = d2h_doubles(c0, jac_out, d_jac, npairs * (size_t)ncols, st);
+    if (rc) return rc;
+  }
+  for (size_t t = 0; t < ncfg; ++t)
+    if (role[t] == 0 && vals_out) return d2h_doubles(c0, vals_out, dv + t * npairs, npairs, st);
+  return SK_OK;
+}
+

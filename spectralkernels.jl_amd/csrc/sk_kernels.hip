@@ -2142,6 +2142,28 @@ void launch_fill_cov(const double* vals, long long npts, double* out, hipStream_
   hipLaunchKernelGGL(k_fill_cov, dim3(nblk(npts * npts, 256)), dim3(256), 0, st, vals, npts, out);
 }
 
+// Jacobian assembly of gen_kernel_jacobian (src/derivatives.jl:100-111) for one row per point pair: column col[t] takes
+// integrand t (role 1: dK/dtheta_j, dK/dalpha); the warping columns take K' times d lag / d warp-parameter (role 2,
+// kernel_warping_gradients :46-54: the chain rule through the warped lag).  map = {role, col} per integrand, then
+// the nwarp warping columns.
+__global__ void k_jac_assemble(const double* vals, long long n, int ncfg, const int* map, const double* dlag, int nwarp,
+                               int t_warp, int ncols, double* jac) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double* row = jac + e * ncols;
+  for (int c = 0; c < ncols; ++c) row[c] = 0.0;
+  for (int t = 0; t < ncfg; ++t)
+    if (map[2 * t] == 1) row[map[2 * t + 1]] = vals[(long long)t * n + e];
+  if (nwarp > 0) {
+    const double kp = vals[(long long)t_warp * n + e];
+    for (int q = 0; q < nwarp; ++q) row[map[2 * ncfg + q]] = kp * dlag[e * nwarp + q];
+  }
+}
+void launch_jac_assemble(const double* vals, long long n, int ncfg, const int* map, const double* dlag, int nwarp, int t_warp,
+                         int ncols, double* jac, hipStream_t st) {
+  hipLaunchKernelGGL(k_jac_assemble, dim3(nblk(n, 256)), dim3(256), 0, st, vals, n, ncfg, map, dlag, nwarp, t_warp, ncols, jac);
+}
+
 __global__ void k_check_sorted(const double* xs, long long n, int* flags) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

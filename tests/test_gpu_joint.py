@@ -119,3 +119,39 @@ def test_joint_march_unsorted_duplicates_and_cost(sk):
     idx = np.searchsorted(np.unique(xs), xs)
     assert np.array_equal(vu, ref[:, idx])
     assert cfgs[0].last_stats()["n_unique"] == np.unique(xs).size
+
+
+def test_jacobian_pairs_matches_the_reference_jacobian_test(sk):
+    # test/derivatives/jacobian.jl:4-33: iso_sdf(w, a) = exp(-a |w|), K = 2a / (a^2 + (2 pi r)^2), warp(p, x) = x^p,
+    # params (a, p) = (1.1, 0.1), 20 points in [0, 1], tol = 1e-12; J_test vs the closed-form Jacobian to 1e-8.
+    # Here: lags of the warped point pairs on the device, one joint march for K, dK/da and K', Jacobian assembled
+    # on the device with d lag / d p supplied by the caller (the reference differentiates the warp with AD, :46-54).
+    a, pw = 1.1, 0.1
+    x = np.linspace(0.0, 1.0, 20)
+    wx = x ** pw
+    jj, kk = np.triu_indices(20)
+    pairs = np.stack([jj, kk], 1)
+    f = sk.SDF.exponential(a)
+    kw = dict(tol=1e-12)
+    cfgs = [sk.AdaptiveKernelConfig(f, **kw), sk.AdaptiveKernelConfig(f.d(0), **kw), sk.AdaptiveKernelConfig(f, derivative=True, **kw)]
+    k0 = sk.compute_k0(cfgs[0])
+    assert abs(k0 - 2.0 / a) <= 1e-10
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dwx = np.where(x > 0, wx * np.log(np.where(x > 0, x, 1.0)), 0.0)  # d(x^p)/dp
+    diff = wx[jj] - wx[kk]
+    dlag = (np.sign(diff) * (dwx[jj] - dwx[kk])).reshape(-1, 1)
+    vals, J = sk.kernel_jacobian_pairs(cfgs, roles=[0, 1, 2], cols=[0, 0, 0], pts=wx, pairs=pairs, k0=k0, dlag=dlag,
+                                       warp_cols=[1], ncols=2)
+    r = np.abs(diff)
+    q = a * a + (2 * np.pi * r) ** 2
+    K = 2 * a / q
+    dK_da = 2.0 / q - 4 * a * a / q ** 2
+    dK_dr = -2 * a * 8 * np.pi ** 2 * r / q ** 2
+    assert np.abs(vals - K).max() < 1e-8
+    assert np.abs(J[:, 0] - dK_da).max() < 1e-8 and np.abs(J[:, 1] - dK_dr * dlag[:, 0]).max() < 1e-8
+    # the values are what kernel_values_pairs (the lookup table of src/model.jl:76-77) returns, within tol
+    v2, _ = sk.kernel_values_pairs(cfgs[0], wx, pairs, k0=k0)
+    assert np.abs(vals - v2).max() <= 1e-11 * k0
+    with pytest.raises(sk.SpectralKernelsError) as ex:  # an index pair out of range is reported, not dereferenced
+        sk.kernel_jacobian_pairs(cfgs, [0, 1, 2], [0, 0, 0], wx, np.array([[0, 25]]), k0, dlag=dlag[:1], warp_cols=[1], ncols=2)
+    assert ex.value.code == 1
