@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--shard", default="strided", choices=("strided", "blocked"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true")
+    ap.add_argument("--no-launch-floor", action="store_true",
+                    help="skip the launch-floor measurement (profiling passes: its empty launches would enter the kernel averages)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="lags in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend at N > 1: nccl (= RCCL over xGMI; the driver's runs) or gloo "
@@ -305,7 +307,7 @@ def main():
                 break
         except Exception:
             pass
-    floor = cfg.launch_floor()
+    floor = {} if args.no_launch_floor else cfg.launch_floor()
     roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": rl[dom]["gbps"], "peak": peak, "unit": "GB/s",
                 "frac": rl[dom]["gbps"] / peak, "traffic": traffic, "avg_us": rl[dom]["avg_us"],
                 "algorithmic_bytes_per_launch": rl[dom]["bytes"],

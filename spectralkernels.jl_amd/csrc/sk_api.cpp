@@ -1272,6 +1272,13 @@ int sk_launch_floor(sk_config* cfg, int reps, double* us4) {
   fin.rhi_for = -1;
   HIPCHK(hipMemcpy(&cfg->db.state[0], &fin, sizeof(fin), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(&cfg->db.state[1], &fin, sizeof(fin), hipMemcpyHostToDevice));
+  // lags of its own: k_interp2 reads xs[min(i, n-1)] ahead of the state, and the last call's array may be gone
+  const long long nfl = 1 << 20;
+  double* d_fl = nullptr;
+  HIPCHK(hipMalloc((void**)&d_fl, nfl * sizeof(double)));
+  HIPCHK(hipMemset(d_fl, 0, nfl * sizeof(double)));
+  DevBuffers dbf = cfg->db;
+  dbf.xs = d_fl;
   hipEvent_t a, b;
   HIPCHK(hipEventCreate(&a));
   HIPCHK(hipEventCreate(&b));
@@ -1280,8 +1287,8 @@ int sk_launch_floor(sk_config* cfg, int reps, double* us4) {
     (void)hipEventRecord(a, st);
     for (int q = 0; q < count; ++q) {
       if (which == 0) launch_empty(grid, st);
-      else if (which == 1) launch_genspread(cfg->dc, cfg->d_ec, cfg->db, SK_MODE_ASIS, 0, 0, 0.0, 0.0, st);
-      else launch_interp(cfg->dc, cfg->d_ec, cfg->db, 0, 1000000, SK_RAW_NONE, st);
+      else if (which == 1) launch_genspread(cfg->dc, cfg->d_ec, dbf, SK_MODE_ASIS, 0, nfl, 0.0, 0.0, st);
+      else launch_interp(cfg->dc, cfg->d_ec, dbf, 0, nfl, SK_RAW_NONE, st);
     }
     (void)hipEventRecord(b, st);
     (void)hipEventSynchronize(b);
@@ -1298,6 +1305,7 @@ int sk_launch_floor(sk_config* cfg, int reps, double* us4) {
   us4[3] = bracket(0, reps) / reps;
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
+  (void)hipFree(d_fl);
   HIPCHK(hipGetLastError());
   return SK_OK;
 }
