@@ -455,8 +455,11 @@ __device__ __forceinline__ void check_input_lags(const DevBuffers& db, long long
     bad |= !(x >= 0.0);
     unsorted |= (i + 1 < n) && !(x < db.xs[i + 1]);
   }
-  if (__any(unsorted) && (threadIdx.x & 63) == 0 && !db.flags[0]) atomicOr(&db.flags[0], 1);
-  if (__any(bad) && (threadIdx.x & 63) == 0 && !db.flags[1]) atomicOr(&db.flags[1], 1);
+  // at most one atomic per wave, none once the flag is up (device-scope pre-check, see k_check_sorted)
+  if (__any(unsorted) && (threadIdx.x & 63) == 0 && !__hip_atomic_load(&db.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicOr(&db.flags[0], 1);
+  if (__any(bad) && (threadIdx.x & 63) == 0 && !__hip_atomic_load(&db.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicOr(&db.flags[1], 1);
 }
 
 // Node, Gauss weight and SDF value of quadrature node j of `rule` (updatequadbufs!, src/quadrature.jl:49-95):
@@ -1964,7 +1967,8 @@ void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, 
   } else if (g_interp_variant == 1) {
     SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp<W, SK_RAW_NONE>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
   } else {
-    SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp2<W, 7>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
+    // 7 waves per SIMD up to W = 12; the wider kernels need a few registers more (6 waves: no spills)
+    SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp2<W, (W >= 14 ? 6 : 7)>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
   }
 }
 
@@ -2166,13 +2170,20 @@ void launch_jac_assemble(const double* vals, long long n, int ncfg, const int* m
 
 __global__ void k_check_sorted(const double* xs, long long n, int* flags) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double x = xs[i];
-  bool bad = !(x >= 0.0);  // negative or NaN
-  bool unsorted = (i + 1 < n) && !(x < xs[i + 1]);
-  // plain read first: on unsorted input every wave would otherwise hit the same address (180 us at 1e6 lags)
-  if (__any(unsorted) && (threadIdx.x & 63) == 0 && !flags[0]) atomicOr(&flags[0], 1);
-  if (__any(bad) && (threadIdx.x & 63) == 0 && !flags[1]) atomicOr(&flags[1], 1);
+  bool bad = false, unsorted = false;
+  if (i < n) {
+    const double x = xs[i];
+    bad = !(x >= 0.0);  // negative or NaN
+    unsorted = (i + 1 < n) && !(x < xs[i + 1]);
+  }
+  // One atomic per workgroup at most, and none once the flag is up: on unsorted input every wave used to hit the
+  // same address (65 us at 1e6 pairwise lags).  The pre-check is a device-scope load: a plain one keeps being
+  // served the stale zero by this CU's L1.
+  const int any_uns = __syncthreads_or(unsorted ? 1 : 0), any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (threadIdx.x == 0) {
+    if (any_uns && !__hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&flags[0], 1);
+    if (any_bad && !__hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&flags[1], 1);
+  }
 }
 void launch_check_sorted(const double* xs, long long n, int* flags, hipStream_t st) {
   hipLaunchKernelGGL(k_check_sorted, dim3(nblk(n, 256)), dim3(256), 0, st, xs, n, flags);
