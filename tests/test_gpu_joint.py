@@ -155,3 +155,25 @@ def test_jacobian_pairs_matches_the_reference_jacobian_test(sk):
     with pytest.raises(sk.SpectralKernelsError) as ex:  # an index pair out of range is reported, not dereferenced
         sk.kernel_jacobian_pairs(cfgs, [0, 1, 2], [0, 0, 0], wx, np.array([[0, 25]]), k0, dlag=dlag[:1], warp_cols=[1], ncols=2)
     assert ex.value.code == 1
+
+
+@pytest.mark.parametrize("criteria", ["both", "panel", "tails"])
+def test_joint_march_with_bisection_and_criteria(sk, oracle, criteria):
+    # a narrow SDF on a tiny rule: the first outer panel is bisected repeatedly (the P buffers of every integrand
+    # carry the accepted sub-panel sums, src/quadrature.jl:257-271), all three convergence criteria
+    tol = 1e-7
+    f = sk.SDF.matern(1.0, 0.05, 1.5)
+    kw = dict(quadspec=(32, 4), tol=tol, convergence_criteria=criteria)
+    cfgs = [sk.AdaptiveKernelConfig(f, **kw), sk.AdaptiveKernelConfig(f, derivative=True, **kw),
+            sk.AdaptiveKernelConfig(f.d(1), **kw)]
+    pds = [False, False, True]
+    rs = np.r_[0.0, 10.0 ** np.linspace(-3, 0.5, 700)]
+    k0 = sk.compute_k0(cfgs[0])
+    vj, ej = sk.kernel_values_joint(cfgs, rs, k0, param_derivative=pds)
+    tr = cfgs[0].last_trace()
+    assert any(not r["accepted"] for r in tr)  # bisection happened
+    for t, (c, pd) in enumerate(zip(cfgs, pds)):
+        v, e = sk.kernel_values(c, rs, k0=k0, param_derivative=pd)
+        assert np.abs(vj[t] - v).max() <= 2 * tol * abs(k0), (t, np.abs(vj[t] - v).max() / abs(k0))
+    truth = oracle.matern_cov(rs, (1.0, 0.05, 1.5))
+    assert np.abs(vj[0] - truth).max() / abs(k0) <= 10 * tol
