@@ -4,7 +4,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 os.environ["SPECTRALKERNELS_HIP_LIB"] = os.path.join(ROOT, "tools", "diag", "libsk_stamps.so")
 os.environ["SK_STAMP_FILE"] = "/tmp/stamps.bin"
-import torch
 import spectralkernels_jl_amd as sk
 cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5))
 rs = 10.0 ** np.linspace(-6, 0, 10 ** 6)

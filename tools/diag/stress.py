@@ -4,7 +4,6 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-import torch  # noqa: F401  (loads its ROCm runtime first)
 import spectralkernels_jl_amd as sk
 from oracle import sk_oracle as oracle
 

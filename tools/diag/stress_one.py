@@ -3,7 +3,6 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-import torch  # noqa: F401
 import spectralkernels_jl_amd as sk
 from oracle import sk_oracle as oracle
 seed = int(sys.argv[1])
