@@ -5,10 +5,17 @@ sys.path.insert(0, ROOT)
 os.environ["SPECTRALKERNELS_HIP_LIB"] = os.path.join(ROOT, "tools", "diag", "libsk_stamps.so")
 os.environ["SK_STAMP_FILE"] = "/tmp/stamps.bin"
 import spectralkernels_jl_amd as sk
-cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5))
-rs = 10.0 ** np.linspace(-6, 0, 10 ** 6)
+wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
+if wl == "C5":  # tol 1e-12, small rule, generic Matern exponent
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(2.14, 0.97, 0.89), tol=1e-12, quadspec=(256, 16))
+    rs = np.linspace(0.0, 5.1, 10 ** 5)
+    k0 = sk.compute_k0(cfg)
+else:
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5))
+    rs = 10.0 ** np.linspace(-6, 0, 10 ** 6)
+    k0 = np.pi / 2
 for _ in range(3):
-    sk.kernel_values(cfg, rs, k0=np.pi / 2)
+    sk.kernel_values(cfg, rs, k0=k0)
 raw = np.fromfile("/tmp/stamps.bin", dtype=np.uint64).reshape(-1, 8)
 a = raw[:6000]
 a = a[a[:, 0] > 0]
