@@ -61,6 +61,53 @@ __device__ __forceinline__ double2 cis_turns_prod(double a, double b) {
   return cis_turns_small(fr + e);
 }
 
+// ---- wave-wide maxima of non-negative values through DPP.  __shfl_xor is a ds_bpermute per dword (the LDS pipe, a
+// round trip and a wait per butterfly step) plus the lane-index arithmetic: ~9 vector instructions per step for a
+// double.  The DPP row operations below move a dword between lanes inside the VALU: 3 instructions per step
+// (v_max_f64 takes no DPP operand, so the halves are moved and the maximum taken separately).  Lanes without a source
+// (row_bcast into row 0) read 0, the identity of the maximum here.  Every lane of the wave must be active.
+template <int CTRL>
+__device__ __forceinline__ int dpp_move(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+// v_max_f64 without the canonicalising self-maxima that fmax() adds around values that went through integer
+// registers; neither operand may be NaN.  (The compiler counts the asm statement as a vector write for the two wait
+// states a DPP read of a freshly written VGPR needs: it puts an s_nop 1 behind it.)
+__device__ __forceinline__ double max_f64_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_max_step(double x) {
+  const int lo = dpp_move<CTRL>(__double2loint(x)), hi = dpp_move<CTRL>(__double2hiint(x));
+  return max_f64_raw(x, __hiloint2double(hi, lo));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max_step(unsigned x) {
+  const unsigned o = (unsigned)dpp_move<CTRL>((int)x);
+  return o > x ? o : x;
+}
+template <class T>
+__device__ __forceinline__ T wave_max_rows(T x) {
+  x = dpp_max_step<0xB1>(x);   // quad_perm [1,0,3,2]
+  x = dpp_max_step<0x4E>(x);   // quad_perm [2,3,0,1]
+  x = dpp_max_step<0x141>(x);  // row_half_mirror
+  x = dpp_max_step<0x140>(x);  // row_mirror: every lane now holds the maximum of its row of 16
+  x = dpp_max_step<0x142>(x);  // row_bcast15: each row takes in lane 15 of the row before it
+  x = dpp_max_step<0x143>(x);  // row_bcast31: rows 2 and 3 take in lane 31 -- lane 63 holds the maximum
+  return x;
+}
+// maximum over the 64 lanes, the same value returned in every lane (a NaN counts as 0: it is reported through the
+// nan flags, never through the maximum)
+__device__ __forceinline__ double wave_max(double x) {
+  x = wave_max_rows(fmax(x, 0.0));
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+__device__ __forceinline__ unsigned wave_max(unsigned x) {
+  return (unsigned)__builtin_amdgcn_readlane((int)wave_max_rows(x), 63);
+}
+
 __device__ __forceinline__ double sdf_eval_dev(int kind, const double* prm, double w) {
   // prm[7] = 0: the SDF itself; j >= 1: its derivative with respect to catalogue parameter j - 1 (the integrands of
   // kernel_sdf_derivatives, src/derivatives.jl:61-72)
@@ -331,11 +378,8 @@ __device__ void step_state(DevState& sh, const DevConst& dc, const DevBuffers& d
     const Reductions& rd = db.red[(t - 1) & 1];
     double m = __longlong_as_double((long long)rd.max_bits[threadIdx.x]);
     unsigned int h = rd.hi[threadIdx.x];
-    for (int off = 32; off > 0; off >>= 1) {
-      m = fmax(m, __shfl_xor(m, off, 64));
-      const unsigned int o = __shfl_xor(h, off, 64);
-      h = o > h ? o : h;
-    }
+    m = wave_max(m);
+    h = wave_max(h);
     if (threadIdx.x == 0) {
       r_max = m;
       r_hi = h;
@@ -1163,9 +1207,9 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
     }
   }
   if constexpr (RAW != SK_RAW_NONE) return;
-  // wave reductions by shuffles (same-address LDS atomics from 64 lanes serialise and were 10 us slower),
-  // then one LDS slot per wave; NaNs are carried by the flags (fmax drops them)
-  for (int off = 32; off > 0; off >>= 1) emax = fmax(emax, __shfl_xor(emax, off, 64));
+  // wave reductions in registers (same-address LDS atomics from 64 lanes serialise and were 10 us slower),
+  // then one LDS slot per wave; NaNs are carried by the flags (wave_max drops them)
+  emax = wave_max(emax);
   // the lag index ascends with the lane: the wave's highest unconverged lag sits in the highest flagged lane
   const unsigned long long um = __ballot(unconv != 0u);
   const unsigned int wave_unconv = um ? (unsigned int)(blk0 + (threadIdx.x & ~63u) + (63 - __builtin_clzll(um)) + 1) : 0u;
@@ -1248,15 +1292,18 @@ __global__ void __launch_bounds__(256, WAVES) k_interp2(DevConst dc, const EsCon
   tail.crit = const_load(&s.tail.crit);
   const int conf = const_load(&s.conf), has_acc = const_load(&s.has_acc), pc = const_load(&s.pc),
             p_valid = const_load(&s.p_valid), stack_len = const_load(&s.stack_len);
-  const double T2 = dc.tol * const_load(&s.k0abs) * 0.5;
+  const double k0abs = const_load(&s.k0abs);
+  const double T2 = dc.tol * k0abs * 0.5;
   const long long ix1 = const_load(&s.ix1), hi = const_load(&s.hi);
+  // the state is wave-uniform (SGPRs): non-finite doubles are found by their exponent bits on the scalar unit -- an
+  // x != x is a vector compare per value (25 vector instructions per wave for this expression before)
+  auto nonfinite = [](double x) { return (unsigned)(((unsigned)__double2hiint(x) & 0x7ff00000u) == 0x7ff00000u); };
   const unsigned bad = (unsigned)(done != 0) | (unsigned)(sn != n) | (unsigned)((unsigned long long)ix1 > 1ull) |
                        (unsigned)(hi < 0) | (unsigned)(hi > n) | (unsigned)((unsigned)conf > 1u) | (unsigned)((unsigned)pc > 1u) |
                        (unsigned)((unsigned)stack_len > (unsigned)kStackCap) | (unsigned)((unsigned)pp.jacobi > 1u) |
                        (unsigned)((unsigned)has_acc > 1u) | (unsigned)((unsigned)p_valid > 1u) |
-                       (unsigned)((unsigned)tail.crit > 2u) | (unsigned)(T2 != T2) | (unsigned)(pp.r_hi != pp.r_hi) |
-                       (unsigned)(pp.tau != pp.tau) | (unsigned)(pp.Cx != pp.Cx) | (unsigned)(pp.theta_scale != pp.theta_scale) |
-                       (unsigned)(pp.inv_rc != pp.inv_rc);
+                       (unsigned)((unsigned)tail.crit > 2u) | nonfinite(k0abs) | nonfinite(pp.r_hi) | nonfinite(pp.tau) |
+                       nonfinite(pp.Cx) | nonfinite(pp.theta_scale) | nonfinite(pp.inv_rc);
   if (bad | (unsigned)(blk0 >= hi)) {
     // Never taken (slot is 0 or 1): a use of the early loads on this side of the branch keeps them ahead of it --
     // the compiler would otherwise sink them below the branch, behind the state's round trip.  (No store here: a
@@ -1408,7 +1455,7 @@ __global__ void __launch_bounds__(256, WAVES) k_interp2(DevConst dc, const EsCon
       pOut[i] = pk;
     }
   }
-  for (int off = 32; off > 0; off >>= 1) emax = fmax(emax, __shfl_xor(emax, off, 64));
+  emax = wave_max(emax);
   const unsigned long long um = __ballot(unconv != 0u);
   const unsigned int wave_unconv = um ? (unsigned int)(blk0 + (threadIdx.x & ~63u) + (63 - __builtin_clzll(um)) + 1) : 0u;
   const int a1f = __any(n1f), a2f = __any(n2f);
@@ -1492,11 +1539,8 @@ __device__ __forceinline__ void block_reduce(const DevBuffers& db, int slot, dou
   __shared__ double smax[4];
   __shared__ unsigned int shi[4];
   __shared__ int sflag[4][2];
-  for (int off = 32; off > 0; off >>= 1) {
-    emax = fmax(emax, __shfl_xor(emax, off, 64));
-    const unsigned int o2 = __shfl_xor(unconv, off, 64);
-    unconv = o2 > unconv ? o2 : unconv;
-  }
+  emax = wave_max(emax);
+  unconv = wave_max(unconv);
   const int a1 = __any(n1f), a2 = __any(n2f);
   if ((threadIdx.x & 63) == 0) {
     smax[threadIdx.x >> 6] = emax;

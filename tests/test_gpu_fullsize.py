@@ -2,8 +2,12 @@
 properties (the direct-sum oracle cannot finish 10^6 lags): closed-form truth within the
 reference's 10*tol acceptance, permutation/duplication invariance, linearity in the SDF
 amplitude, agreement of a thinned subset with the full run, and the panel schedule."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -180,3 +184,22 @@ def test_sharded_entry_on_the_visible_devices(sk):
     with pytest.raises(sk.SpectralKernelsError) as ex:
         sk.ShardedKernelConfig(sk.SDF.matern(1, 1, 1.5), devices=[0, nd])
     assert ex.value.code == 6
+
+
+def test_roctx_ranges_and_copy_thread_settings_do_not_change_results(sk):
+    # SK_ROCTX=1 (roctx ranges named like the reference's @timeit sections, looked up with dlopen) and SK_COPY_THREADS=1
+    # (single-threaded staging) are read when the library loads: run them in a child process, compare with this one
+    import subprocess
+    import sys as _sys
+    code = ("import numpy as np, spectralkernels_jl_amd as sk\n"
+            "cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5), quadspec=(256, 16))\n"
+            "rs = 10.0 ** np.linspace(-5, 0, 70000)\n"
+            "ks, es = sk.kernel_values(cfg, rs, k0=np.pi / 2)\n"
+            "print(repr(float(ks.sum())), repr(float(es.sum())))\n")
+    env = dict(os.environ, SK_ROCTX="1", SK_COPY_THREADS="1", PYTHONPATH=ROOT)
+    out = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    a, b = [float(x) for x in out.stdout.strip().split()[-2:]]
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5), quadspec=(256, 16))
+    ks, es = sk.kernel_values(cfg, 10.0 ** np.linspace(-5, 0, 70000), k0=np.pi / 2)
+    assert a == float(ks.sum()) and b == float(es.sum())

@@ -2,6 +2,9 @@
 usage: devsteps.py [C2|C3|C5] [steps]   (run under rocprofv3 --kernel-trace --stats for per-kernel durations)"""
 import os, sys, time
 import numpy as np
+if os.environ.get("SK_TORCH_FIRST"):  # torch's bundled HIP / rocFFT serve the library then (bench.py at N > 1)
+    import torch
+    torch.cuda.init()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import spectralkernels_jl_amd as sk
 import bench
