@@ -48,7 +48,7 @@ struct JointTr {
   int logmode;     // 0: none; 1 / 2: slots A / B of a logw integrand (src/quadrature.jl:186-228, :243)
   int imag;        // take the imaginary part (sin kernel) instead of the real part (cos kernel)
   int out;         // integrand this transform feeds
-  int pad;
+  int base;        // first transform with the same SDF and parameters prm[0..6] (<= own index): S(w) is evaluated once
   double prm[8];
 };
 struct JointSpec {

@@ -9,6 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include "sk_config.h"
+#include <string>
+#include <vector>
+#include <cstdio>
 
 namespace sk {
 int joint_wait_status(sk_config* cfg, unsigned int seq, hipStream_t st);  // sk_api.cpp (wait_status)
@@ -69,6 +72,12 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
       tr.logmode = a.logw ? (q == 0 ? 1 : 2) : 0;
       tr.imag = a.logw ? q : (a.derivative ? 1 : 0);     // :sin for K' and for slot B (src/quadrature.jl:177,198)
       tr.out = (int)t;
+      tr.base = js.ntr - 1;
+      for (int e = 0; e < js.ntr - 1; ++e)
+        if (js.tr[e].sdf_kind == tr.sdf_kind && std::memcmp(js.tr[e].prm, tr.prm, 7 * sizeof(double)) == 0) {
+          tr.base = e;
+          break;
+        }
     }
   }
   if (n == 0) return SK_OK;
@@ -191,6 +200,13 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
     R = R < 16 ? 2 * R : 16;
   }
   HIPCHK(hipGetLastError());
+#ifdef SK_STAMPS
+  if (const char* f = getenv("SK_STAMP_FILE")) {  // tools/diag/stamps_joint.py
+    std::vector<unsigned long long> h(8 * 8192);
+    (void)hipMemcpy(h.data(), db.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen((std::string(f) + ".joint").c_str(), "wb")) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); }
+  }
+#endif
   c0->stats.n_outer = hs->n_outer;
   c0->stats.n_panels = hs->n_panels;
   c0->stats.n_accepted = hs->n_accepted;

@@ -108,43 +108,49 @@ __device__ __forceinline__ unsigned wave_max(unsigned x) {
   return (unsigned)__builtin_amdgcn_readlane((int)wave_max_rows(x), 63);
 }
 
-__device__ __forceinline__ double sdf_eval_dev(int kind, const double* prm, double w) {
-  // prm[7] = 0: the SDF itself; j >= 1: its derivative with respect to catalogue parameter j - 1 (the integrands of
-  // kernel_sdf_derivatives, src/derivatives.jl:61-72)
-  const int dparam = (int)prm[7];
+// S(w) of the catalogue SDF itself and the auxiliary x that its parameter derivatives share (Matern: rho^2 + w^2)
+__device__ __forceinline__ double sdf_base_dev(int kind, const double* prm, double w, double& x) {
   switch (kind) {
     case SK_SDF_MATERN: {
-      const double x = prm[1] * prm[1] + w * w;
+      x = prm[1] * prm[1] + w * w;
       // prm[4] (set by sk_config_create): 2 (nu + d/2) when that is an integer <= 64, else 0.  Half-integer
       // powers by sqrt and repeated squaring (~2 ulp) instead of the generic pow (~250 instructions).
       const int h = (int)prm[4];
-      double S;
       if (h > 0) {
         double b = (h & 1) ? sqrt(x) : 1.0, sq = x, r = 1.0;
         for (int e = h >> 1; e > 0; e >>= 1) {
           if (e & 1) r *= sq;
           sq *= sq;
         }
-        S = prm[0] / (r * b);
-      } else {
-        S = prm[0] * pow(x, -prm[2] - prm[3] * 0.5);
+        return prm[0] / (r * b);
       }
-      if (dparam == 0) return S;
+      return prm[0] * pow(x, -prm[2] - prm[3] * 0.5);
+    }
+    case SK_SDF_EXPONENTIAL: x = fabs(w); return exp(-prm[0] * x);
+    case SK_SDF_GAUSSIAN: x = w * w; return exp(-x / (prm[0] * prm[0]));
+    default: x = 0.0; return __builtin_nan("");
+  }
+}
+// derivative of S with respect to catalogue parameter dparam - 1 from S and x of sdf_base_dev (the integrands of
+// kernel_sdf_derivatives, src/derivatives.jl:61-72)
+__device__ __forceinline__ double sdf_dparam_dev(int kind, const double* prm, int dparam, double S, double x, double w) {
+  switch (kind) {
+    case SK_SDF_MATERN:
       if (dparam == 1) return S / prm[0];                                        // d/dphi
       if (dparam == 2) return S * (-prm[2] - prm[3] * 0.5) * 2.0 * prm[1] / x;    // d/drho
       if (dparam == 3) return -S * log(x);                                       // d/dnu
       return __builtin_nan("");
-    }
-    case SK_SDF_EXPONENTIAL: {
-      const double S = exp(-prm[0] * fabs(w));
-      return dparam == 0 ? S : (dparam == 1 ? -fabs(w) * S : __builtin_nan(""));
-    }
-    case SK_SDF_GAUSSIAN: {
-      const double S = exp(-(w * w) / (prm[0] * prm[0]));
-      return dparam == 0 ? S : (dparam == 1 ? S * 2.0 * w * w / (prm[0] * prm[0] * prm[0]) : __builtin_nan(""));
-    }
+    case SK_SDF_EXPONENTIAL: return dparam == 1 ? -x * S : __builtin_nan("");
+    case SK_SDF_GAUSSIAN: return dparam == 1 ? S * 2.0 * w * w / (prm[0] * prm[0] * prm[0]) : __builtin_nan("");
     default: return __builtin_nan("");
   }
+}
+__device__ __forceinline__ double sdf_eval_dev(int kind, const double* prm, double w) {
+  // prm[7] = 0: the SDF itself; j >= 1: its derivative with respect to catalogue parameter j - 1
+  double x;
+  const double S = sdf_base_dev(kind, prm, w, x);
+  const int dparam = (int)prm[7];
+  return dparam == 0 ? S : sdf_dparam_dev(kind, prm, dparam, S, x, w);
 }
 
 // dS/dw of the catalogue (the `df` keyword, src/adaptive.jl:24; only the logw first panel needs it)
@@ -454,25 +460,59 @@ __global__ void __launch_bounds__(64) k_advance(DevConst dc, DevBuffers db, int 
 
 // ------------------------------------------------------------------ ES kernel evaluation
 
-// Even/odd Horner evaluation of pair q at offset y: E(y^2), O(y^2).  `poly` is a kernel-argument
-// pointer and q is a compile-time constant after unrolling, so the coefficient loads are scalar.
-template <int W>
-__device__ __forceinline__ void es_pair(const double* poly, int q, double y2, double& E, double& O) {
+// A read-only table seen through the constant address space: its uniform-address loads are scalar loads whatever
+// else the kernel does.  Through a plain pointer the compiler only emits scalar loads while it can prove that
+// nothing ahead of them may write memory -- a store, an atomic or even an opaque intrinsic ahead of the table
+// loads silently turns them into uniform-address vector loads (+17 us on k_interp when it happened).
+typedef const double __attribute__((address_space(4))) * const_table;
+__device__ __forceinline__ const_table as_const_table(const double* p) { return (const_table)(unsigned long long)p; }
+// one value of memory that no other kernel writes while this one runs (state of the step, lags), read the same way
+template <class T>
+__device__ __forceinline__ T const_load(const T* p) {
+  return *(const T __attribute__((address_space(4)))*)(unsigned long long)p;
+}
+
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4): no destination registers, the
+// wave's lanes land at lds_wave_base + lane x 16 (a wave-uniform base -- not a per-lane scatter); counted by vmcnt.
+__device__ __forceinline__ void lds_dma16(const double2* src, double2* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// The W ES-kernel weights of a lag with kernel offset y, tables read by scalar loads (k_interp & co).
+// The even/odd polynomials are summed against precomputed powers of y^2 with the coefficient as the
+// *multiplicand*: v_fmac_f64 acc, s[coef], v[power].  Horner (E = E*y2 + coef) puts the SGPR coefficient in
+// the addend, and the compiler then copies every coefficient into a VGPR pair first (2 v_mov_b32 per step:
+// 200 of k_interp's 590 VALU instructions per wave, found with SQ_INSTS_VALU / the ISA histogram).
+template <int W, class TablePtr>
+__device__ __forceinline__ void es_weights(TablePtr poly, double y, double (&wt)[W]) {
   constexpr int NCO = W / 2 + 1;
-  const double* pe = poly + q * 2 * NCO;
-  const double* po = pe + NCO;
-  E = pe[0];
-  O = po[0];
+  const double y2 = y * y;
+  double pw[NCO];  // pw[i] = y2^i
+  pw[0] = 1.0;
+  pw[1] = y2;
 #pragma unroll
-  for (int i = 1; i < NCO; ++i) {
-    E = fma(E, y2, pe[i]);
-    O = fma(O, y2, po[i]);
+  for (int i = 2; i < NCO; ++i) pw[i] = pw[i - 1] * y2;
+#pragma unroll
+  for (int q = 0; q < W / 2; ++q) {
+    const auto pe = poly + q * 2 * NCO;  // highest power first
+    const auto po = pe + NCO;
+    double E = pe[0] * pw[NCO - 1], O = po[0] * pw[NCO - 1];
+#pragma unroll
+    for (int i = 1; i < NCO - 1; ++i) {  // smallest terms first
+      E = fma(pe[i], pw[NCO - 1 - i], E);
+      O = fma(po[i], pw[NCO - 1 - i], O);
+    }
+    E += pe[NCO - 1];
+    O += po[NCO - 1];
+    wt[q] = fma(y, O, E);
+    wt[W - 1 - q] = fma(-y, O, E);
   }
 }
 
-// Stages the ES tables (device memory) in LDS for k_spread, whose table reads come after LDS/global
-// stores.  k_interp reads them with scalar loads instead: a same-address LDS broadcast still returns
-// 16 B to every lane, and ~50 of them per wave cost as much LDS bandwidth as all the FP64 VALU work.
+// Stages the ES tables (device memory) in LDS -- the seam test kernel only.  The march's kernels read them with scalar
+// loads (const_table): a same-address LDS broadcast still returns 16 B to every lane, and ~50 of them per wave cost
+// as much LDS bandwidth as all the FP64 VALU work.
 template <int W>
 __device__ __forceinline__ void stage_es_tables(const EsConst* __restrict__ ecp, double* s_poly, double* s_cheb) {
   const EsConst& ec = *ecp;
@@ -612,7 +652,6 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
   __shared__ double2 s_c[kSpreadThreads];
   __shared__ int s_l0[kSpreadThreads];
   __shared__ double2 s_red[kSpreadThreads];
-  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
   __shared__ DevState sh;
   const int slot = FUSED ? (slot_or_t & 1) : slot_or_t;
 #ifdef SK_STAMPS
@@ -646,7 +685,6 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
   const unsigned long long tk1 = __builtin_amdgcn_s_memtime();
   int nitems = 0;
 #endif
-  stage_es_tables<W>(ec, s_poly, nullptr);  // made visible by the first barrier of the tile loop
   // Work items: the variant's tiles (heaviest first).  The separate kernel is launched with one workgroup per
   // item; the fused one with a grid that is resident at once, so that the state prologue is paid once per
   // workgroup slot (items are taken with stride gridDim.x).
@@ -698,7 +736,7 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
       J0 = cs[L - W / 2 < 0 ? 0 : L - W / 2];
       J1 = cs[L + W / 2 > (int)n1 ? (int)n1 : L + W / 2];
     }
-    __syncthreads();  // ES tables staged; previous item's s_red consumed
+    __syncthreads();  // previous item's s_red consumed
 #ifdef SK_STAMPS
     t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -729,16 +767,15 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
           const double tcn = P - 0.5 * W;
           const double l0d = ceil(tcn);
           const double y = (l0d - tcn) - 0.5;
-          const double y2 = y * y;
           s_l0[sidx] = (int)l0d - L0;
           double* wrow = &s_w[sidx * (W + 1)];
+          // coefficients as scalar operands (s_load through the constant address space, see const_table) instead of
+          // one broadcast LDS read per coefficient from a staged copy: 7 W LDS instructions per source less
+          // (k_spread<12,true> at C2: 21.1 -> 19.1 us)
+          double wt[W];
+          es_weights<W>(as_const_table(ec->poly), y, wt);
 #pragma unroll
-          for (int qq = 0; qq < W / 2; ++qq) {
-            double E, O;
-            es_pair<W>(s_poly, qq, y2, E, O);
-            wrow[qq] = fma(y, O, E);
-            wrow[W - 1 - qq] = fma(-y, O, E);
-          }
+          for (int q = 0; q < W; ++q) wrow[q] = wt[q];
         }
       }
       __syncthreads();
@@ -825,7 +862,6 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
   __shared__ double s_w[NB * (W + 1)];
   __shared__ double2 s_ck[NT * NB];
   __shared__ int s_l0[NB];
-  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
   const DevState& s = db.state[slot];
   if (s.done) return;
   if (!state_sane(s, db, s.n)) return;
@@ -864,8 +900,6 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
     J0 = cs[L - W / 2 < 0 ? 0 : L - W / 2];
     J1 = cs[L + W / 2 > (int)n1 ? (int)n1 : L + W / 2];
   }
-  stage_es_tables<W>(ec, s_poly, nullptr);
-  __syncthreads();
   double ar[TPW], ai[TPW];
 #pragma unroll
   for (int q = 0; q < TPW; ++q) { ar[q] = 0.0; ai[q] = 0.0; }
@@ -876,16 +910,12 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
       const double tcn = P - 0.5 * W;
       const double l0d = ceil(tcn);
       const double y = (l0d - tcn) - 0.5;
-      const double y2 = y * y;
       s_l0[tid] = (int)l0d - L0;
       double* wrow = &s_w[tid * (W + 1)];
+      double wt[W];
+      es_weights<W>(as_const_table(ec->poly), y, wt);  // scalar-loaded coefficients (see k_spread)
 #pragma unroll
-      for (int qq = 0; qq < W / 2; ++qq) {
-        double E, O;
-        es_pair<W>(s_poly, qq, y2, E, O);
-        wrow[qq] = fma(y, O, E);
-        wrow[W - 1 - qq] = fma(-y, O, E);
-      }
+      for (int q = 0; q < W; ++q) wrow[q] = wt[q];
     }
     if (tid >= NB && tid - NB < nb) {  // the other two waves: strengths of all terms of source jb + tid - NB
       const int jj = tid - NB;
@@ -955,49 +985,6 @@ __device__ __forceinline__ int tap_base(double r, double r_hi, double inv_rc, do
   const double k0d = ceil(tcn);
   y = (k0d - tcn) - 0.5;
   return (int)fmin(fmax(k0d, -(double)(n2 / 2)), (double)(n2 / 2 - W)) + n2 / 2;
-}
-
-// A read-only table seen through the constant address space: its uniform-address loads are scalar loads whatever
-// else the kernel does.  Through a plain pointer the compiler only emits scalar loads while it can prove that
-// nothing ahead of them may write memory -- a store, an atomic or even an opaque intrinsic ahead of the table
-// loads silently turns them into uniform-address vector loads (+17 us on k_interp when it happened).
-typedef const double __attribute__((address_space(4))) * const_table;
-__device__ __forceinline__ const_table as_const_table(const double* p) { return (const_table)(unsigned long long)p; }
-// one value of memory that no other kernel writes while this one runs (state of the step, lags), read the same way
-template <class T>
-__device__ __forceinline__ T const_load(const T* p) {
-  return *(const T __attribute__((address_space(4)))*)(unsigned long long)p;
-}
-
-// The W ES-kernel weights of a lag with kernel offset y, tables read by scalar loads (k_interp & co).
-// The even/odd polynomials are summed against precomputed powers of y^2 with the coefficient as the
-// *multiplicand*: v_fmac_f64 acc, s[coef], v[power].  Horner (E = E*y2 + coef) puts the SGPR coefficient in
-// the addend, and the compiler then copies every coefficient into a VGPR pair first (2 v_mov_b32 per step:
-// 200 of k_interp's 590 VALU instructions per wave, found with SQ_INSTS_VALU / the ISA histogram).
-template <int W, class TablePtr>
-__device__ __forceinline__ void es_weights(TablePtr poly, double y, double (&wt)[W]) {
-  constexpr int NCO = W / 2 + 1;
-  const double y2 = y * y;
-  double pw[NCO];  // pw[i] = y2^i
-  pw[0] = 1.0;
-  pw[1] = y2;
-#pragma unroll
-  for (int i = 2; i < NCO; ++i) pw[i] = pw[i - 1] * y2;
-#pragma unroll
-  for (int q = 0; q < W / 2; ++q) {
-    const auto pe = poly + q * 2 * NCO;  // highest power first
-    const auto po = pe + NCO;
-    double E = pe[0] * pw[NCO - 1], O = po[0] * pw[NCO - 1];
-#pragma unroll
-    for (int i = 1; i < NCO - 1; ++i) {  // smallest terms first
-      E = fma(pe[i], pw[NCO - 1 - i], E);
-      O = fma(po[i], pw[NCO - 1 - i], O);
-    }
-    E += pe[NCO - 1];
-    O += po[NCO - 1];
-    wt[q] = fma(y, O, E);
-    wt[W - 1 - q] = fma(-y, O, E);
-  }
 }
 
 // H = sum_q taps[q] * wt[q] for one or two rules (taps: W consecutive FFT-output samples, global or LDS)
