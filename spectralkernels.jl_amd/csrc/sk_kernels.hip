@@ -416,6 +416,64 @@ __device__ void step_state(DevState& sh, const DevConst& dc, const DevBuffers& d
   __syncthreads();
 }
 
+// step_state for the fused k_spread: ONE wave produces the state of step `t` on its own -- loads, reduction of the
+// slots, transition, publication -- while the other waves of the workgroup do work that needs no state (the kernel
+// weights of their first tile); the caller's next __syncthreads() makes `sh` visible to them.  All 64 lanes of the
+// calling wave must be active.  LDS operations of one wave execute in order: lane 0 reads what its wave wrote.
+__device__ void step_state_wave(DevState& sh, const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0,
+                                double ks0, bool lead) {
+  const int lane = (int)(threadIdx.x & 63u);
+  constexpr unsigned NDW = sizeof(DevState) / 4;
+  constexpr int NV = (int)((NDW + 63) / 64);
+  double red_max = 0.0;
+  unsigned int red_hi = 0u;
+  int red_nan = 0;
+  if (mode != SK_MODE_INIT) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(&db.state[(mode == SK_MODE_TRANSITION ? t - 1 : t) & 1]);
+    unsigned* dst = reinterpret_cast<unsigned*>(&sh);
+    unsigned v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const unsigned q = (unsigned)lane + 64u * k;
+      v[k] = q < NDW ? src[q] : 0u;
+    }
+    if (mode == SK_MODE_TRANSITION) {  // in flight together with the state
+      const Reductions& rd = db.red[(t - 1) & 1];
+      red_max = __longlong_as_double((long long)rd.max_bits[lane]);
+      red_hi = rd.hi[lane];
+      red_nan = rd.nan;
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const unsigned q = (unsigned)lane + 64u * k;
+      if (q < NDW) dst[q] = v[k];
+    }
+    if (mode == SK_MODE_TRANSITION) {
+      red_max = wave_max(red_max);
+      red_hi = wave_max(red_hi);
+    }
+  }
+  if (lane == 0) {
+    if (mode == SK_MODE_INIT) {
+      init_state(sh, dc, db, n, k0, ks0);
+      if (lead && sh.ix1 == 1) {  // src/adaptive.jl:132-146
+        db.ks[0] = ks0;
+        db.errs[0] = __builtin_nan("");
+      }
+    } else if (mode == SK_MODE_TRANSITION) {
+      transition(sh, dc, db, red_max, red_hi, red_nan, lead);
+    }
+    if (!sh.done && !state_sane(sh, db, n)) sh.done = -SK_EHIP;
+    if (lead && (mode != SK_MODE_ASIS || sh.done == -SK_EHIP)) db.state[t & 1] = sh;
+  }
+  if (lead) {  // reset the reduction slots that k_interp(t) will accumulate into (last read by step t - 1)
+    Reductions& rn = db.red[t & 1];
+    rn.max_bits[lane] = 0ull;
+    rn.hi[lane] = 0u;
+    if (lane == 0) rn.nan = 0;
+  }
+}
+
 // Deferred tail fit of a new outer panel (see setup_outer).
 __device__ void resolve_tail(DevState& s, const DevConst& dc) {
   if (s.done || !s.tail_pending) return;
@@ -657,17 +715,99 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
 #ifdef SK_STAMPS
   const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
 #endif
+  const int tid = threadIdx.x;
+  const int64_t n1 = dc.n1, n2 = dc.n2;
+  // ---- a work item (tile): header, lane mapping and the loads of its first batch, issued before any barrier
+  int rule = 0, L0 = 0, ncell = 0, jlo = 0, jhi = 0, sidx = 0, role = 2, spl = 1, cell = 0, sub = 0, J0 = 0, J1 = 0;
+  bool coop = false;
+  const double* __restrict__ pos = nullptr;
+  const double2* __restrict__ src = nullptr;
+  double P_next = 0.0;
+  double2 c_next = make_double2(0.0, 0.0);
+  NodeRef nr_next;
+  nr_next.no = nr_next.wt = 0.0;
+  nr_next.sp = 0;
+  const int lane = tid & 63;
+  const int part = tid >> 6;
+  constexpr int NPART = kSpreadThreads / 64;
+  auto begin_item = [&](int item, int var) {
+    const int4 tl = dc.tiles[var][item];  // {rule<<30 | first cell, cells, first source, end source}
+    rule = (tl.x >> 30) & 1;
+    L0 = tl.x & 0x3fffffff;
+    ncell = tl.y;
+    jlo = tl.z;
+    jhi = tl.w;
+    const int* __restrict__ cs = dc.cellstart[var][rule];
+    pos = dc.pos[var][rule];
+    src = db.src + (rule ? dc.M : 0);
+    P_next = 0.0;
+    c_next = make_double2(0.0, 0.0);
+    nr_next.no = nr_next.wt = 0.0;
+    nr_next.sp = 0;
+    // FUSED, at most 128 touching sources (most tiles): two threads share a source -- waves 0-1 make its kernel
+    // weights, waves 2-3 its strength -- which halves the staging phase, the longest of an item
+    coop = FUSED && (jhi - jlo) <= kSpreadThreads / 2;
+    sidx = coop ? (tid & (kSpreadThreads / 2 - 1)) : tid;  // source slot of this thread within a batch
+    role = coop ? (tid >> 7) : 2;                           // 0: weights, 1: strength, 2: both
+    if (jlo + sidx < jhi) {
+      P_next = pos[jlo + sidx];
+      if constexpr (FUSED) {
+        if (role != 0) nr_next = node_fetch(dc, var, rule, jlo + sidx);
+      } else {
+        c_next = src[jlo + sidx];
+      }
+    }
+    // lane mapping: tiles at the sub-panel edges have few cells but many sources, so the 64 lanes of
+    // a wave are split as (cell, sub): `spl` lanes share one cell and take strided sources
+    int c2 = 64;
+    while (c2 / 2 >= ncell && c2 > 1) c2 >>= 1;  // smallest power of two >= ncell (<= 64)
+    spl = 64 / c2;
+    cell = lane / spl;
+    sub = lane - cell * spl;
+    // sources touching cell L have floor(P_j) in [L - W/2, L + W/2): a contiguous range of the sorted list
+    J0 = J1 = 0;
+    if (cell < ncell) {
+      const int L = L0 + cell;
+      J0 = cs[L - W / 2 < 0 ? 0 : L - W / 2];
+      J1 = cs[L + W / 2 > (int)n1 ? (int)n1 : L + W / 2];
+    }
+  };
+  // the W kernel weights and the first cell of the source at grid position P into this thread's staging slot
+  auto stage_weights = [&](double P) {
+    const double tcn = P - 0.5 * W;
+    const double l0d = ceil(tcn);
+    const double y = (l0d - tcn) - 0.5;
+    s_l0[sidx] = (int)l0d - L0;
+    double* wrow = &s_w[sidx * (W + 1)];
+    // coefficients as scalar operands (s_load through the constant address space, see const_table) instead of
+    // one broadcast LDS read per coefficient from a staged copy: 7 W LDS instructions per source less
+    // (k_spread<12,true> at C2: 21.1 -> 19.1 us)
+    double wt[W];
+    es_weights<W>(as_const_table(ec->poly), y, wt);
+#pragma unroll
+    for (int q = 0; q < W; ++q) wrow[q] = wt[q];
+  };
+  // FUSED: the state of this step is produced by the last wave alone (step_state_wave) while the others already
+  // stage the kernel weights of their first tile -- those need the tile list only, and that is variant 0 on every
+  // panel but a Jacobi one (p != 0 and a == 0: the first panel of a march), where the early work is discarded.
+  // (The state chain -- a round trip for the previous state and the reduction slots, the serial transition, a
+  // barrier -- was as long as a whole tile: C2 0.1195 -> 0.1173 ms, C5 1.280 -> 1.237 ms per step, same box.)
+  bool pre = false;
   if constexpr (FUSED) {
-    step_state(sh, dc, db, mode, slot_or_t, n, k0, ks0, blockIdx.x == gridDim.x - 1);
+    if ((int)blockIdx.x < dc.ntiles[0]) {
+      begin_item((int)blockIdx.x, 0);
+      pre = true;
+    }
+    if (part == NPART - 1) step_state_wave(sh, dc, db, mode, slot_or_t, n, k0, ks0, blockIdx.x == gridDim.x - 1);
+    if (pre && jlo + sidx < jhi && role != 1) stage_weights(P_next);
+    __syncthreads();
     if (mode == SK_MODE_INIT && db.check_input) check_input_lags(db, n);
   }
   const DevState& s = FUSED ? sh : db.state[slot];
   if (s.done) return;
   if (!state_sane(s, db, s.n)) return;
   const int variant = FUSED ? __builtin_amdgcn_readfirstlane(s.pp.jacobi) : s.pp.jacobi;
-  const int64_t n1 = dc.n1, n2 = dc.n2;
   const int ntiles = dc.ntiles[variant];
-  const int tid = threadIdx.x;
   PanelParams pp;
   if constexpr (FUSED) {
     // wave-uniform values read from LDS: move them to SGPRs
@@ -693,49 +833,8 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     ++nitems;
 #endif
-    const int4 tl = dc.tiles[variant][item];  // {rule<<30 | first cell, cells, first source, end source}
-    const int rule = (tl.x >> 30) & 1;
-    const int L0 = tl.x & 0x3fffffff;
-    const int ncell = tl.y;
-    const int jlo = tl.z, jhi = tl.w;
-    const int* __restrict__ cs = dc.cellstart[variant][rule];
-    const double* __restrict__ pos = dc.pos[variant][rule];
-    const double2* __restrict__ src = db.src + (rule ? dc.M : 0);
-    // first batch's loads are issued before the barrier
-    double P_next = 0.0;
-    double2 c_next = make_double2(0.0, 0.0);
-    NodeRef nr_next;
-    nr_next.no = nr_next.wt = 0.0;
-    nr_next.sp = 0;
-    // FUSED, at most 128 touching sources (most tiles): two threads share a source -- waves 0-1 make its kernel
-    // weights, waves 2-3 its strength -- which halves the staging phase, the longest of an item
-    const bool coop = FUSED && (jhi - jlo) <= kSpreadThreads / 2;
-    const int sidx = coop ? (tid & (kSpreadThreads / 2 - 1)) : tid;  // source slot of this thread within a batch
-    const int role = coop ? (tid >> 7) : 2;                           // 0: weights, 1: strength, 2: both
-    if (jlo + sidx < jhi) {
-      P_next = pos[jlo + sidx];
-      if constexpr (FUSED) {
-        if (role != 0) nr_next = node_fetch(dc, variant, rule, jlo + sidx);
-      } else {
-        c_next = src[jlo + sidx];
-      }
-    }
-    // lane mapping: tiles at the sub-panel edges have few cells but many sources, so the 64 lanes of
-    // a wave are split as (cell, sub): `spl` lanes share one cell and take strided sources
-    int c2 = 64;
-    while (c2 / 2 >= ncell && c2 > 1) c2 >>= 1;  // smallest power of two >= ncell (<= 64)
-    const int spl = 64 / c2;
-    const int lane = tid & 63;
-    const int part = tid >> 6;
-    constexpr int NPART = kSpreadThreads / 64;
-    const int cell = lane / spl, sub = lane - cell * spl;
-    // sources touching cell L have floor(P_j) in [L - W/2, L + W/2): a contiguous range of the sorted list
-    int J0 = 0, J1 = 0;
-    if (cell < ncell) {
-      const int L = L0 + cell;
-      J0 = cs[L - W / 2 < 0 ? 0 : L - W / 2];
-      J1 = cs[L + W / 2 > (int)n1 ? (int)n1 : L + W / 2];
-    }
+    const bool staged = pre && variant == 0 && item == (int)blockIdx.x;  // header and first weights done ahead of the state
+    if (!staged) begin_item(item, variant);
     __syncthreads();  // previous item's s_red consumed
 #ifdef SK_STAMPS
     t1 = __builtin_amdgcn_s_memtime();
@@ -763,20 +862,7 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
             c_next = src[j + kSpreadThreads];
           }
         }
-        if (role != 1) {
-          const double tcn = P - 0.5 * W;
-          const double l0d = ceil(tcn);
-          const double y = (l0d - tcn) - 0.5;
-          s_l0[sidx] = (int)l0d - L0;
-          double* wrow = &s_w[sidx * (W + 1)];
-          // coefficients as scalar operands (s_load through the constant address space, see const_table) instead of
-          // one broadcast LDS read per coefficient from a staged copy: 7 W LDS instructions per source less
-          // (k_spread<12,true> at C2: 21.1 -> 19.1 us)
-          double wt[W];
-          es_weights<W>(as_const_table(ec->poly), y, wt);
-#pragma unroll
-          for (int q = 0; q < W; ++q) wrow[q] = wt[q];
-        }
+        if (role != 1 && !(staged && jb == jlo)) stage_weights(P);
       }
       __syncthreads();
 #ifdef SK_STAMPS
