@@ -829,7 +829,8 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
   // item; the fused one with a grid that is resident at once, so that the state prologue is paid once per
   // workgroup slot (items are taken with stride gridDim.x: the workgroups that start first -- lowest index -- hold the
   // heaviest tiles and the extra ones of a last, partial round.  Handing the extras to the workgroups with the lightest
-  // tiles instead was 1 us slower: those are dispatched last).
+  // tiles instead was 1 us slower: those are dispatched last.  Issuing the next tile's header loads before this tile's
+  // output phase: +0.5 us, twelve more live registers in the gather loop).
   for (int item = blockIdx.x; item < ntiles; item += gridDim.x) {
 #ifdef SK_STAMPS
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
