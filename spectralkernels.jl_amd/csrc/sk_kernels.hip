@@ -791,7 +791,7 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
   // stage the kernel weights of their first tile -- those need the tile list only, and that is variant 0 on every
   // panel but a Jacobi one (p != 0 and a == 0: the first panel of a march), where the early work is discarded.
   // (The state chain -- a round trip for the previous state and the reduction slots, the serial transition, a
-  // barrier -- was as long as a whole tile: C2 0.1195 -> 0.1173 ms, C5 1.280 -> 1.237 ms per step, same box.)
+  // barrier -- was as long as a whole tile: C2 0.1193 -> 0.1182 ms, C5 1.270 -> 1.237 ms per step, same box.)
   bool pre = false;
   if constexpr (FUSED) {
     if ((int)blockIdx.x < dc.ntiles[0]) {
