@@ -112,8 +112,8 @@ def timed(fn, steps, warmup, fence):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--shard", default="strided", choices=("strided", "blocked"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -319,6 +319,19 @@ def main():
                 "launch_floor_us": floor}
     if "spread" in roofline["per_kernel"]:
         roofline["per_kernel"]["spread"]["launch_floor_us"] = floor.get("spread_prologue_only")
+    # the dominant kernel's other roofline: vector-instruction issue.  Dynamic instructions per wave from the committed
+    # PMC passes (profiles/r02_interp_instmix.json), one wave instruction per SIMD every 4 cycles, 1024 SIMDs at the
+    # 2.4 GHz peak clock -- the bound that explains why the kernel sits at a fifth of the HBM peak
+    try:
+        mix = json.load(open(os.path.join(ROOT, "profiles", "%s_interp_instmix.json" % ROUND))).get(str(cfg.nufft_width))
+        if dom == "interp" and mix:
+            waves = 4.0 * (acc["interp"]["active_items"] / acc["interp"]["launches"]) / 256.0
+            issue_us = waves * mix["valu_per_wave"] * 4.0 / (1024 * 2.4e3)
+            roofline["valu_issue"] = {"valu_insts_per_wave": mix["valu_per_wave"], "fp64_insts_per_wave": mix["fp64_fma_add_mul_per_wave"],
+                                      "waves_per_launch": waves, "issue_us_at_peak_clock": issue_us,
+                                      "frac_of_issue_peak": issue_us / rl["interp"]["avg_us"]}
+    except Exception:
+        pass
     # whole-step view: algorithmic bytes per lag (24 + 40*abar + 48*M*Q/N) over the step time
     abar = st["sum_active"] / max(1, st["n_unique"])
     bytes_per_lag = 24.0 + 40.0 * abar + 48.0 * M * st["n_panels"] / max(1, n)
