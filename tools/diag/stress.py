@@ -1,6 +1,8 @@
 """One-off randomised stress run against the oracle (wider than tests/test_gpu_random.py): dims 1 and 2,
 derivative, logw, sorted / unsorted / duplicated lags.  python tools/diag/stress.py [n_seeds]"""
 import os, sys, time
+import functools
+print = functools.partial(print, flush=True)  # gpurun takes seven silent minutes for a hang
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
