@@ -1352,6 +1352,9 @@ __global__ void __launch_bounds__(256) k_interp(DevConst dc, const EsConst* ec, 
 // ~70 % utilisation, then the last of 2.2 rounds of workgroups drains at falling occupancy for a quarter of the launch.
 // Computing the kernel weights while the window is in flight instead of behind the barrier, for grids of at most
 // two workgroups per CU where nothing else hides the scalar table loads: 7.7 us either way on C5 (1e5 lags).
+// Two lags per lane (512-lag workgroups: state, table and reduction overhead paid once for two lags, every scalar-loaded
+// coefficient feeding two FMA chains; 90 registers, 5 waves): identical results, 23.95 against 23.40 us at 1e6 lags
+// and 12.4 against 9.3 us at 1e5 (half the workgroups) -- the instructions saved were not the ones that bound it.
 // Tried on top of this and measured slower: 5 or 8 waves per SIMD (23.9 / 24.5 us; 8 needs spills), one wave per
 // workgroup with per-wave windows and per-wave global atomics (132 us: four times the atomics on the same few cache
 // lines serialise in L2), the same with the reduction through LDS by the last wave to arrive (24.9 us).
