@@ -1,6 +1,7 @@
 """One-off randomised stress run against the oracle (wider than tests/test_gpu_random.py): dims 1 and 2,
 derivative, logw, sorted / unsorted / duplicated lags.  python tools/diag/stress.py [n_seeds]"""
 import os, sys, time
+os.environ.setdefault("OMP_NUM_THREADS", "16")  # the oracle: 256 logical CPUs are visible on the GPU box, a fraction is ours
 import functools
 print = functools.partial(print, flush=True)  # gpurun takes seven silent minutes for a hang
 import numpy as np
