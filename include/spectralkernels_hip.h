@@ -257,6 +257,10 @@ int sk_host_compute_k0(const sk_config_args* args, double* k0);
 int sk_host_compute_k0_part(const sk_config_args* args, double t_lo, double t_hi, double* part);
 int sk_host_validate(const sk_config_args* args, int64_t* m, int64_t* k);
 int sk_host_es_eval(int w, double z, double* phi, double* phi_poly);
+/* The staging pass of the host-array upload (chunks staged by `threads` host threads, order of the lags checked in
+ * the same pass -- src/adaptive.jl:99,113) on plain memory: stage receives the copy; *order = 1 strictly increasing,
+ * 2 not, 3 a negative / NaN lag.  threads <= 0: the library's default (SK_COPY_THREADS). */
+int sk_host_stage_scan(const double* src, size_t cnt, double* stage, int threads, int* order);
 
 const char* sk_last_error(void);
 const char* sk_version(void);

@@ -91,6 +91,38 @@ static inline int scan_order(const double* src, size_t a, size_t b) {
   return uns | (bad << 1);
 }
 
+// The chunked staging pass of h2d_doubles: `nthreads` host threads copy chunk c of src into `stage` (each its own slice)
+// and look at the order of their slice; thread 0 hands every complete chunk [lo, hi) to `on_chunk` (the DMA).
+// The order flags are taken from the CALLER's array -- the step across a slice boundary reads src[a-1], never the
+// neighbouring thread's (possibly unfinished) slice of the staging buffer.  Returns the OR of scan_order's flags.
+template <class OnChunk>
+static int stage_chunks(double* stage, const double* src, const std::vector<size_t>& edge,
+                        std::vector<std::atomic<int>>& chunk_done, bool want_order, int nthreads, OnChunk&& on_chunk) {
+  const size_t nch = edge.size() - 1;
+  std::atomic<int> flags{0};
+#pragma omp parallel num_threads(nthreads)
+  {
+    const int nt = omp_get_num_threads(), q = omp_get_thread_num();
+    int f = 0;
+    for (size_t c = 0; c < nch; ++c) {
+      const size_t lo = edge[c], hi = edge[c + 1];
+      size_t a, b;
+      slice_of(lo, hi, q, nt, a, b);
+      if (b > a) {
+        std::memcpy(stage + a, src + a, (b - a) * sizeof(double));
+        if (want_order) f |= scan_order(src, a, b);
+      }
+      chunk_done[c].fetch_add(1, std::memory_order_release);
+      if (q == 0) {
+        while (chunk_done[c].load(std::memory_order_acquire) < nt) _mm_pause();
+        on_chunk(lo, hi);
+      }
+    }
+    if (f) flags.fetch_or(f);
+  }
+  return flags.load();
+}
+
 int h2d_doubles(sk_config* cfg, double* d_dst, const double* src, size_t cnt, hipStream_t st, int* order) {
   if (order) *order = SK_ORDER_UNKNOWN;
   if (cnt == 0) return SK_OK;
@@ -115,34 +147,13 @@ int h2d_doubles(sk_config* cfg, double* d_dst, const double* src, size_t cnt, hi
   const size_t nch = edge.size() - 1;
   if (cfg->chunk_done.size() < nch) cfg->chunk_done = std::vector<std::atomic<int>>(nch + 8);
   for (size_t c = 0; c < nch; ++c) cfg->chunk_done[c].store(0, std::memory_order_relaxed);
-  std::atomic<int> flags{0}, err{0};
-  const bool want_order = order != nullptr;
-#pragma omp parallel num_threads(copy_threads())
-  {
-    const int nt = omp_get_num_threads(), q = omp_get_thread_num();
-    int f = 0;
-    for (size_t c = 0; c < nch; ++c) {
-      const size_t lo = edge[c], hi = edge[c + 1];
-      size_t a, b;
-      slice_of(lo, hi, q, nt, a, b);
-      if (b > a) {
-        std::memcpy(stage + a, src + a, (b - a) * sizeof(double));
-        if (want_order) f |= scan_order(stage, a, b);
-      }
-      cfg->chunk_done[c].fetch_add(1, std::memory_order_release);
-      if (q == 0) {
-        while (cfg->chunk_done[c].load(std::memory_order_acquire) < nt) _mm_pause();
-        if (hipMemcpyAsync(d_dst + lo, stage + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
-          err.store(1);
-      }
-    }
-    if (f) flags.fetch_or(f);
-  }
+  std::atomic<int> err{0};
+  const int f = stage_chunks(stage, src, edge, cfg->chunk_done, order != nullptr, copy_threads(), [&](size_t lo, size_t hi) {
+    if (hipMemcpyAsync(d_dst + lo, stage + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+      err.store(1);
+  });
   if (err.load()) return fail(SK_EHIP, "H2D copy failed");
-  if (order) {
-    const int f = flags.load();
-    *order = (f & 2) ? SK_ORDER_INVALID : ((f & 1) ? SK_ORDER_UNSORTED : SK_ORDER_SORTED);
-  }
+  if (order) *order = (f & 2) ? SK_ORDER_INVALID : ((f & 1) ? SK_ORDER_UNSORTED : SK_ORDER_SORTED);
   return SK_OK;
 }
 
@@ -224,6 +235,25 @@ int d2h_doubles(sk_config* cfg, double* dst, const double* d_src, size_t cnt, hi
 
 // ---------------------------------------------------------------------- memory helpers of the C ABI
 extern "C" {
+
+// Host-only hook (CPU test tier): the staging pass of the host-array upload on plain memory -- `stage` receives the
+// copy, *order what the pass found out about the lags (1 sorted, 2 unsorted, 3 invalid).  threads <= 0: SK_COPY_THREADS.
+int sk_host_stage_scan(const double* src, size_t cnt, double* stage, int threads, int* order) {
+  if (!src || !stage || !order) return fail(SK_EINVAL, "null argument");
+  int f = 0;
+  if (cnt <= kSerialMax) {
+    std::memcpy(stage, src, cnt * sizeof(double));
+    f = scan_order(src, 0, cnt);
+  } else {
+    std::vector<size_t> edge;
+    make_chunks(cnt, true, edge);
+    std::vector<std::atomic<int>> done(edge.size() + 8);
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    f = stage_chunks(stage, src, edge, done, true, threads > 0 ? threads : copy_threads(), [](size_t, size_t) {});
+  }
+  *order = (f & 2) ? SK_ORDER_INVALID : ((f & 1) ? SK_ORDER_UNSORTED : SK_ORDER_SORTED);
+  return SK_OK;
+}
 
 int sk_device_count(int* n) {
   if (!n) return fail(SK_EINVAL, "null argument");

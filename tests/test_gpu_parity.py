@@ -472,3 +472,43 @@ def test_higher_even_dims(sk, oracle, dim):
     cfg_h = sk.AdaptiveKernelConfig(sk.SDF.matern(*parms, dim), hankel_min_lags=1, **kw)
     kh, _ = sk.kernel_values(cfg_h, rs2, k0=k0)
     assert np.abs(kh - oracle.matern_cov(rs2, parms, d=dim)).max() / k0 <= 10 * 1e-8
+
+
+def test_all_nan_sdf_hip_and_oracle_agree(sk, oracle):
+    # src/quadrature.jl:165 precedence: a NaN in int1 suppresses the throw; both sides bisect down to the guard
+    bad = sk.AdaptiveKernelConfig(lambda w: w * float("nan"), quadspec=(8, 2), sdf="callback")
+    obad = oracle.AdaptiveKernelConfig(lambda w: w * float("nan"), quadspec=(8, 2))
+    rs = np.array([0.5, 1.0])
+    with pytest.raises(sk.SpectralKernelsError) as e:
+        sk.kernel_values(bad, rs, k0=1.0)
+    with pytest.raises(RuntimeError) as oe:
+        oracle.kernel_values(obad, rs, k0=1.0)
+    assert e.value.code == 2 and "split too many times" in str(e.value) and "split too many times" in str(oe.value)
+
+
+def test_stress_seed27_derivative_tol1e10_within_the_oracles_own_spread(sk, oracle):
+    """VERDICT r2 weak #1 (tools/diag/repro_seed.py 27 48): derivative=true, tol 1e-10, quadspec (128, 8), ~12 000
+    panels with per-lag contributions at the convergence threshold.  The oracle itself moves by `spread` when its
+    thresholds shift by 1e-4 relative (tests/test_oracle_pinning.py); HIP must sit inside that spread and be as
+    close to the closed form as the oracle is."""
+    from seed27 import seed27_case
+    rs, k0, mk, truth = seed27_case(oracle)
+    oks, _, otr = oracle.kernel_values(mk(oracle), rs, k0=k0, return_trace=True)
+    oks2, _ = oracle.kernel_values(mk(oracle), rs, k0=k0 * (1 + 1e-4))
+    spread = np.abs(oks - oks2).max() / abs(k0)
+    cfg = mk(sk)
+    ks, errs = sk.kernel_values(cfg, rs, k0=k0)
+    st = cfg.last_stats()
+    d = np.abs(ks - oks).max() / abs(k0)
+    assert d <= 1.5 * spread + 1e-11, (d, spread)
+    e_hip, e_or = np.abs(ks - truth).max() / abs(k0), np.abs(oks - truth).max() / abs(k0)
+    assert e_hip <= 1.5 * e_or, (e_hip, e_or)
+    assert abs(st["n_panels"] - len(otr)) <= 0.1 * len(otr)   # a schedule of the same length class
+    # the two traces agree until the first knife-edge decision: the common prefix is long (thousands of panels)
+    tr = cfg.last_trace()
+    m = min(len(tr), len(otr))
+    same = 0
+    while same < m and (tr[same]["a"], tr[same]["b"], bool(tr[same]["accepted"])) == (
+            otr[same]["a"], otr[same]["b"], bool(otr[same]["accepted"])):
+        same += 1
+    assert same >= 1000, same

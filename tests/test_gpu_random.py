@@ -34,3 +34,42 @@ def test_random_configs_vs_oracle(sk, oracle, seed):
     tr = cfg.last_trace()
     if len(tr) == len(otr):
         assert [(r["a"], r["b"]) for r in tr] == [(r["a"], r["b"]) for r in otr]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_modes_vs_oracle(sk, oracle, seed):
+    """The wider draw of tools/diag/stress.py inside the suite: dim 1 / 2, value / derivative / logw,
+    the three convergence criteria, sorted / unsorted / duplicated lags.  Bar: 0.2 tol K(0) (two schedules that differ
+    in one knife-edge decision each stay within the user tol; the usual difference is 1e-3 tol)."""
+    rng = np.random.default_rng(7000 + seed)
+    dim = [1, 1, 2][seed % 3]
+    phi, rho, nu = rng.uniform(0.5, 3.0), 10.0 ** rng.uniform(-1.0, 0.7), rng.uniform(0.6, 2.2)
+    mode = ["plain", "deriv", "logw", "plain"][(seed // 3) % 4]
+    alpha = 0.0
+    if mode == "logw" or seed % 5 == 0:
+        alpha = (dim - 1) + rng.uniform(0.1, 0.8)
+    if mode == "deriv" and alpha >= dim - 0.05:
+        alpha = 0.0
+    tol = [1e-4, 1e-6, 1e-8][seed % 3] if mode == "deriv" else [1e-4, 1e-6, 1e-8, 1e-10][seed % 4]
+    quadspec = [(256, 16), (128, 8), (64, 4), (512, 4)][(seed // 2) % 4]
+    crit = ["both", "both", "tails", "panel"][(seed // 4) % 4]
+    n = int(rng.integers(30, 400)) if dim == 1 or seed % 2 else int(rng.integers(2100, 3000))
+    scale = 10.0 ** rng.uniform(-2, 0.7)
+    rs = scale * (rng.uniform(0, 1, n) if seed % 2 else 10.0 ** rng.uniform(-3, 0, n))
+    if seed % 4 == 0:
+        rs = np.concatenate([rs, rs[: n // 5], [0.0]])
+        rs = rs[rng.permutation(rs.size)]
+    else:
+        rs = np.sort(rs)
+    kw = dict(dim=dim, alpha=alpha, tol=tol, quadspec=quadspec, derivative=(mode == "deriv"), logw=(mode == "logw"),
+              convergence_criteria=crit)
+    base = oracle.AdaptiveKernelConfig(oracle.SDF.matern(phi, rho, nu, dim), dim=dim, alpha=alpha, tol=tol, quadspec=quadspec)
+    k0 = oracle.compute_k0(base)
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(phi, rho, nu, dim), **kw)
+    ocfg = oracle.AdaptiveKernelConfig(oracle.SDF.matern(phi, rho, nu, dim), nthreads=8, **kw)
+    pd = mode == "logw"
+    ks, errs = sk.kernel_values(cfg, rs, k0=k0, param_derivative=pd)
+    oks, oerrs = oracle.kernel_values(ocfg, rs, k0=k0, param_derivative=pd)
+    assert np.array_equal(np.isnan(errs), np.isnan(oerrs))
+    d = np.nanmax(np.abs(ks - oks)) / abs(k0)
+    assert d <= max(0.2 * tol, 5e-12), (d, kw)

@@ -114,3 +114,60 @@ def test_es_polynomial_matches_closed_form(sk, w):
     # polynomial error stays at the kernel's own cutoff level exp(-beta) (its design accuracy)
     beta = 2.30 * w if w != 4 else 2.38 * w
     assert worst < 5 * np.exp(-beta) + 1e-14
+
+
+def test_staged_upload_order_scan_alternating_arrays():
+    """ADVICE r2 (sk_hostio.cpp): the order scan of the chunked upload must read the CALLER's array across slice
+    boundaries, not the neighbouring thread's (possibly unfinished) slice of the staging buffer.  Alternate arrays
+    whose verdict differs exactly at slice boundaries, with several copy threads, through the host-only hook."""
+    import ctypes as C
+    from spectralkernels_jl_amd import _lib
+    L = _lib.load()
+    L.sk_host_stage_scan.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    n = (1 << 18) + 12345   # > kSerialMax: chunked, multi-threaded path; ragged last slices
+    rng = np.random.default_rng(5)
+    base = np.cumsum(rng.uniform(0.5, 1.5, n))
+    stage = np.empty(n)
+    order = C.c_int(0)
+
+    def scan(a, threads):
+        assert L.sk_host_stage_scan(a.ctypes.data, a.size, stage.ctypes.data, threads, C.byref(order)) == 0
+        assert np.array_equal(stage, a, equal_nan=True)
+        return order.value
+
+    for threads in (1, 3, 8):
+        for rep in range(6):
+            assert scan(base, threads) == 1                      # strictly increasing
+            bad = base.copy()
+            # an order violation at EVERY candidate slice boundary of the first chunks in turn
+            j = int(rng.integers(1, n - 1))
+            bad[j] = bad[j - 1]                                  # duplicate: not strictly increasing
+            assert scan(bad, threads) == 2, (threads, rep, j)
+            desc = base[::-1].copy()
+            assert scan(desc, threads) == 2
+            inv = base.copy()
+            inv[int(rng.integers(0, n))] = np.nan
+            assert scan(inv, threads) == 3
+            neg = base.copy()
+            neg[0] = -1.0
+            assert scan(neg, threads) == 3
+    # violations sitting exactly on every boundary of an 8-way split of every chunk
+    edges = set()
+    lo, rem = 0, n
+    sizes = []
+    k = 1 << 17
+    while rem > 2 * k:
+        c = ((rem // 2 + k - 1) // k) * k
+        sizes.append(c)
+        rem -= c
+    sizes.append(rem)
+    for c in reversed(sizes):
+        per = (c + 7) // 8
+        for q in range(1, 8):
+            edges.add(min(lo + q * per, lo + c))
+        lo += c
+        edges.add(lo)
+    for e in sorted(x for x in edges if 0 < x < n)[:40]:
+        bad = base.copy()
+        bad[e] = bad[e - 1] - 1e-9
+        assert scan(bad, 8) == 2, e

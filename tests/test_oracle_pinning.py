@@ -247,3 +247,38 @@ def test_derivative_high_accuracy_stops_short_by_truncation(oracle):
         lead = 2.0 * b_i * float(S(b_i)) * abs(np.cos(2 * np.pi * b_i * xs[i])) / xs[i] / k0
         assert 0.5 * lead <= missing <= 2.0 * lead              # ... by the tail it did not see
         assert errs[i] / k0 < 0.01 * tol                        # and its own error estimate does not know
+
+
+def test_nan_precedence_follows_the_reference(oracle):
+    """src/quadrature.jl:165: `any(isnan, int1) || any(isnan, int2) && throw(...)` only throws when int1 is NaN-free.
+    An SDF that is NaN everywhere poisons both rules: no throw, the panel is never accepted and is bisected down to
+    the b - a < 1e-16 guard (src/utils.jl:28-36) -- the product's SK_ESUBDIVIDE, not SK_ENAN."""
+    import pytest as _pt
+    cfg = oracle.AdaptiveKernelConfig(lambda w: w * float("nan"), quadspec=(8, 2))
+    with _pt.raises(RuntimeError) as e:
+        oracle.kernel_values(cfg, np.array([0.5, 1.0]), k0=1.0)
+    assert "split too many times" in str(e.value)
+    # NaN in the 2m-rule only (a pole that only the finer rule's nodes hit is not constructible robustly; emulate
+    # with a closure that is NaN on a set of measure zero hit by no node: stays finite) -> plain success
+    ok = oracle.AdaptiveKernelConfig(lambda w: np.exp(-w), quadspec=(8, 2))
+    ks, _ = oracle.kernel_values(ok, np.array([0.5, 1.0]), k0=2.0)
+    assert np.all(np.isfinite(ks))
+
+
+def test_derivative_high_accuracy_regime_is_unstable_in_the_oracle_itself(oracle):
+    """stress seed 27 (derivative=true, tol 1e-10, quadspec (128, 8)) -- HIP and oracle end
+    2.4e-7 K(0) apart.  The discriminating experiment on the CPU: shifting the oracle's own thresholds by 1e-4
+    relative (5e-15 K(0) absolute in tol|k0|/2, below any NUFFT's accuracy) changes the ~12 000-panel schedule and
+    moves the oracle's result by the same 2.4e-7 K(0), while its distance to the closed form stays 1.26e-7 K(0):
+    in this regime (the algorithm stops short by ~1000 tol) every schedule is as good as any other."""
+    from seed27 import seed27_case
+    rs, k0, mk, truth = seed27_case(oracle)
+    res = []
+    for eps in (0.0, 1e-4):
+        ks, _, tr = oracle.kernel_values(mk(oracle), rs, k0=k0 * (1 + eps), return_trace=True)
+        res.append((ks, len(tr)))
+    spread = np.abs(res[0][0] - res[1][0]).max() / abs(k0)
+    assert res[0][1] != res[1][1]            # another schedule
+    assert 1e-7 < spread < 1e-6              # ... and a result 2000 tol away
+    for ks, _ in res:                        # both equally far from the truth
+        assert 0.5e-7 < np.abs(ks - truth).max() / abs(k0) < 2e-7
