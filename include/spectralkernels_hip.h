@@ -78,6 +78,8 @@ typedef struct {
   int sdf_dparam;          /* catalogue SDFs: 0 = the SDF itself; j >= 1 = its derivative with respect to
                               sdf_params[j-1] -- the integrands of kernel_sdf_derivatives (src/derivatives.jl:61-72),
                               evaluated on the device.  Matern: phi, rho, nu; exponential, gaussian: a. */
+  int batch_panels;        /* device-resident dim-1 march: most panels evaluated per launch triple (consecutive panels
+                              of equal width share the NUFFT geometry); 0 = choose from the rule size, else 1, 2, 4, 8 */
 } sk_config_args;
 
 typedef struct sk_config sk_config; /* opaque */
@@ -110,6 +112,8 @@ typedef struct {
   int64_t n_steps_launched; /* device steps enqueued incl. speculative ones */
   int64_t n_syncs;       /* host<->device synchronisations */
   double last_b;         /* upper end of the last panel */
+  int64_t n_steps;       /* device steps whose panels were applied (a step evaluates 1..batch_panels panels) */
+  int64_t n_rerun;       /* steps discarded and re-run with fewer panels (a later panel of the batch was rejected) */
 } sk_stats;
 int sk_last_stats(const sk_config* cfg, sk_stats* out);
 

@@ -19,13 +19,14 @@ class ConfigArgs(C.Structure):
                 ("df", SDF_BATCH_FN), ("df_ctx", C.c_void_p), ("dim", C.c_int), ("alpha", C.c_double),
                 ("tol", C.c_double), ("derivative", C.c_int), ("logw", C.c_int), ("criteria", C.c_int),
                 ("has_tail", C.c_int), ("tail", C.c_double), ("m", C.c_int64), ("k", C.c_int64),
-                ("device", C.c_int), ("nufft_width", C.c_int), ("hankel_min_lags", C.c_int), ("sdf_dparam", C.c_int)]
+                ("device", C.c_int), ("nufft_width", C.c_int), ("hankel_min_lags", C.c_int), ("sdf_dparam", C.c_int),
+                ("batch_panels", C.c_int)]
 
 
 class Stats(C.Structure):
     _fields_ = [("n_unique", C.c_int64), ("n_outer", C.c_int64), ("n_panels", C.c_int64), ("n_accepted", C.c_int64),
                 ("sum_active", C.c_int64), ("n_steps_launched", C.c_int64), ("n_syncs", C.c_int64),
-                ("last_b", C.c_double)]
+                ("last_b", C.c_double), ("n_steps", C.c_int64), ("n_rerun", C.c_int64)]
 
 
 K_NAMES = ["gen", "spread", "fft", "interp", "advance"]

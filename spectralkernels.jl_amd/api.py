@@ -74,7 +74,11 @@ class SDF:
 
 _CRIT = {"both": 0, "panel": 1, "tails": 2}
 
-_PROBES = np.array([0.0, 1e-3, 0.017, 0.13, 0.71, 1.0, 2.3, 9.1, 47.0, 3.1e2, 2.2e3])
+# probe frequencies: the first eleven solve for / verify the parameters; the rest reach into the range a march visits
+# (panels end at m k / (2 r), up to ~1e10 for the lags of BASELINE config 3) so that a closure with a cutoff, a band
+# limit or another tail beyond a few thousand is NOT taken for the untapered family
+_PROBES = np.array([0.0, 1e-3, 0.017, 0.13, 0.71, 1.0, 2.3, 9.1, 47.0, 3.1e2, 2.2e3, 1.7e4, 1.3e5, 2.9e6, 7.7e7, 3.3e9,
+                    6.1e10])
 
 
 def recognize_sdf(fn, dim=1, rtol=1e-12):
@@ -90,6 +94,8 @@ def recognize_sdf(fn, dim=1, rtol=1e-12):
     if not np.all(np.isfinite(v)) or not np.all(v[:6] > 0) or np.any(v < 0):
         return None
     w = _PROBES
+    # relative agreement wherever the model is representable; where it underflows (exponential families at the far
+    # probes) the closure must be as small
     ok = lambda model: bool(np.all(np.abs(model - v) <= rtol * np.abs(v) + 1e-300))
     # exponential: log f linear in |w|
     a = -np.log(v[5] / v[0])
@@ -129,9 +135,16 @@ def _check(code):
 
 
 def _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, tail, quadspec, device, nufft_width,
-               hankel_min_lags=0, sdf="auto"):
+               hankel_min_lags=0, sdf="auto", batch_panels=0):
     if not isinstance(f, SDF):
         rec = recognize_sdf(f, dim) if sdf == "auto" else None
+        if rec is not None:
+            # the reference treats f as a black box (src/adaptive.jl:3): say so when it is not evaluated as one
+            warnings.warn("AdaptiveKernelConfig: the SDF closure matches the device catalogue (%s, parameters %s) at %d "
+                          "probe frequencies up to %.1e and is evaluated on the device; pass sdf=\"callback\" to have the "
+                          "closure itself called in batches." % (
+                              {L.SDF_MATERN: "matern", L.SDF_EXPONENTIAL: "exponential", L.SDF_GAUSSIAN: "gaussian"}[rec.kind],
+                              rec.params, _PROBES.size, _PROBES[-1]), stacklevel=3)
         f = rec if rec is not None else SDF.callback(f)
     if convergence_criteria not in _CRIT:
         raise SpectralKernelsError(L.SK_EINVAL, "Argument convergence_criteria must be one of :panel, :tails, :both.")
@@ -170,6 +183,7 @@ def _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, t
     a.device = int(device)
     a.nufft_width = int(nufft_width)
     a.hankel_min_lags = int(hankel_min_lags)
+    a.batch_panels = int(batch_panels)
     a.sdf_dparam = int(getattr(f, "dparam", 0))
     return a, keep, f
 
@@ -180,12 +194,12 @@ class AdaptiveKernelConfig:
 
     def __init__(self, f, df=None, dim=1, alpha=0.0, tol=1e-8, derivative=False, logw=False,
                  convergence_criteria="both", tail=None, quadspec=(2 ** 12, 2 ** 4), device=-1, nufft_width=0,
-                 hankel_min_lags=0, sdf="auto"):
+                 hankel_min_lags=0, sdf="auto", batch_panels=0):
         self._h = None
         lib = L.load()
         self.df, self._device = df, device
         args, self._keep, self.f = _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, tail,
-                                              quadspec, device, nufft_width, hankel_min_lags, sdf)
+                                              quadspec, device, nufft_width, hankel_min_lags, sdf, batch_panels)
         self._args = args
         h = C.c_void_p()
         code = _check(lib.sk_config_create(C.byref(h), C.byref(args)))

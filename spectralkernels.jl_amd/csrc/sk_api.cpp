@@ -67,6 +67,8 @@ static int validate(const sk_config_args& a, int64_t& m, int64_t& k, int& warned
   if (a.alpha >= a.dim) return fail(SK_EINVAL, "alpha must be less than dim to be integrable.");
   if (a.m < 1 || a.k < 1) return fail(SK_EINVAL, "quadspec entries must be positive");
   if (!(a.tol > 0)) return fail(SK_EINVAL, "tol must be positive");
+  if (a.batch_panels != 0 && a.batch_panels != 1 && a.batch_panels != 2 && a.batch_panels != 4 && a.batch_panels != 8)
+    return fail(SK_EINVAL, "batch_panels must be 0 (auto), 1, 2, 4 or 8");
   m = a.m;
   k = a.k;
   warned = 0;
@@ -271,6 +273,14 @@ static int run_fft(sk_config* cfg, hipStream_t st) {
   return SK_OK;
 }
 
+static int run_fft_b(sk_config* cfg, hipStream_t st) {
+  FFTCHK(rocfft_execution_info_set_stream(cfg->info_b, st));
+  void* in[1] = {cfg->db.bfft};
+  void* out[1] = {cfg->db.bfft_out};
+  FFTCHK(rocfft_execute(cfg->plan_b, in, out, cfg->info_b));
+  return SK_OK;
+}
+
 // Waits until k_advance has published status block number `seq` (pinned host memory, polled).
 static int wait_status(sk_config* cfg, unsigned int seq, hipStream_t st) {
   volatile unsigned int* p = &cfg->h_status->seq;
@@ -310,6 +320,12 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   db.P[0] = db.accE[1] + n;
   db.P[1] = db.P[0] + n;
   db.lw_raw = db.P[1] + n;  // 4 n doubles, only allocated (and used) for logw configs
+  // batched march: three buffers each for the running sums and the outer-panel partial sums (9 n doubles)
+  for (int q = 0; q < 3; ++q) {
+    db.bK[q] = d_scratch6n + (size_t)q * n;
+    db.bE[q] = d_scratch6n + (size_t)(3 + q) * n;
+    db.bP[q] = d_scratch6n + (size_t)(6 + q) * n;
+  }
   db.fvals = cfg->d_fvals;
   const bool cb = (cfg->dc.sdf_kind == SK_SDF_CALLBACK);
   const bool logw = cfg->dc.logw != 0;
@@ -329,7 +345,9 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   const DevState* hs = &cfg->h_status->state;
   int t = 0;             // step counter: step t evaluates the panel described by state_t
   int mode = SK_MODE_INIT;
-  int R = host_step ? 1 : 2;
+  // device-resident dim-1 march on a catalogue SDF: batched steps (sk_batch_kernels.inc)
+  const bool batched = !host_step && cfg->dc.dim == 1 && !g_no_fuse;
+  int R = (host_step || batched) ? 1 : 2;
   const int nu_main = cfg->dc.derivative ? cfg->dc.dim / 2 : cfg->dc.dim / 2 - 1;  // src/quadrature.jl:176-180
 
   // callback SDFs: integrand `g` at the nodes of the current (sub)panel, evaluated on the host
@@ -365,14 +383,24 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       int rc = upload_fvals(g, hv);
       if (rc) return rc;
     }
-    const bool fused = !host_step && cfg->dc.dim == 1 && !g_no_fuse;  // catalogue SDF, no log factors
-    if (!fused) { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, g, st); }
-    if (cfg->dc.dim == 1) {
+    if (batched) {
+      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread_b(cfg->dc, cfg->d_ec, db, mode, t, n, k0, ks0, st); }
       {
-        EvScope e(cfg, st, SK_K_SPREAD);
-        if (fused) launch_genspread(cfg->dc, cfg->d_ec, db, mode, t, n, k0, ks0, st);
-        else launch_spread(cfg->dc, cfg->d_ec, db, t & 1, st);
+        EvScope e(cfg, st, SK_K_FFT);
+        int rc = run_fft_b(cfg, st);
+        if (rc) return rc;
       }
+      if (lags_ready) {  // first evaluation: from here on every lag is read
+        HIPCHK(hipStreamWaitEvent(st, lags_ready, 0));
+        lags_ready = nullptr;
+        if (check_flags) launch_check_sorted(d_uxs, n, db.flags, st);
+      }
+      { EvScope e(cfg, st, SK_K_INTERP); launch_interp_b(cfg->dc, cfg->d_ec, db, t & 1, n, st); }
+      return SK_OK;
+    }
+    { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, g, st); }
+    if (cfg->dc.dim == 1) {
+      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->d_ec, db, t & 1, st); }
       {
         EvScope e(cfg, st, SK_K_FFT);
         int rc = run_fft(cfg, st);
@@ -472,7 +500,11 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     }
     if (!host_step) {
       const unsigned int seq = ++cfg->seq;
-      { EvScope e(cfg, st, SK_K_ADVANCE); launch_advance(cfg->dc, db, mode, t, n, k0, ks0, seq, st); }
+      {
+        EvScope e(cfg, st, SK_K_ADVANCE);
+        if (batched) launch_advance_b(cfg->dc, db, mode, t, n, k0, ks0, seq, st);
+        else launch_advance(cfg->dc, db, mode, t, n, k0, ks0, seq, st);
+      }
       int rc = wait_status(cfg, seq, st);
       if (rc) return rc;
       if (cfg->h_status->flags[1] & 2) return fail(SK_EHIP, "internal error: inconsistent device state detected by a kernel guard");
@@ -488,17 +520,20 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   stt.n_accepted = hs->n_accepted;
   stt.sum_active = hs->sum_active;
   stt.last_b = hs->b;
+  stt.n_steps = batched ? hs->n_steps : hs->n_panels;
+  stt.n_rerun = batched ? hs->n_rerun : 0;
   cfg->trace_len = (size_t)hs->trace_len;
   cfg->trace_valid = false;
   if (cfg->profile) {
     HIPCHK(hipStreamSynchronize(st));
     std::memset(&cfg->ktimes, 0, sizeof(cfg->ktimes));
-    // only the first n_panels steps did work; later (speculative) steps exit early
+    // only the first steps did work; later (speculative) steps exit early
+    const long long worked = batched ? hs->n_steps + hs->n_rerun : hs->n_panels;
     int64_t seen[SK_K_COUNT] = {0};
     for (auto& r : cfg->ev_recs) {
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, r.a, r.b);
-      if (r.kid == SK_K_ADVANCE || seen[r.kid]++ < hs->n_panels) {
+      if (r.kid == SK_K_ADVANCE || seen[r.kid]++ < worked) {
         cfg->ktimes.total_ms[r.kid] += ms;
         cfg->ktimes.launches[r.kid] += 1;
       }
@@ -535,7 +570,8 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   if (n > (size_t)0x7fffffff) return fail(SK_EINVAL, "at most 2^31-1 lags per call");
   HIPCHK(hipSetDevice(cfg->device));
   const size_t a8 = ((n * 8 + 255) / 256) * 256;
-  const size_t nscr = cfg->dc.logw ? 10 : 6;  // + 4 n raw panel sums of the logw passes
+  // 6 n running / partial sums (+ 4 n raw panel sums of the logw passes); 9 n on the batched march
+  const size_t nscr = cfg->dc.logw ? 10 : 9;
   int rc = ensure_ws(cfg, nscr * a8);
   if (rc) return rc;
   // Host-array entries have looked at the lags while staging them (sk_hostio.cpp) and say so in `order`.
@@ -713,6 +749,9 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     dc.n1 = next_smooth_even(n1);
     dc.n2 = 2 * dc.n1;
   }
+  // Panels per batched step: the transforms of a step (4 K of length n1) stay at what one default-rule panel pair
+  // costs today (K n1 <= 2^17): two panels per step for the default rule, four for the small rules
+  dc.K = args->batch_panels ? args->batch_panels : (dc.n1 > 40000 ? 2 : 4);
   dc.delta = 2.0 / (double)(dc.n1 - dc.w);
   dc.tau_fac = (double)dc.n2 / (double)(dc.n1 - dc.w);
   dc.log2m = -1;
@@ -777,7 +816,8 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   DA(2, db.state); DA(kStackCap, db.stack); DA(kTraceCap, db.trace);
   DA((size_t)3 * cfg->M, db.src); DA((size_t)2 * dc.n2, db.fft); DA((size_t)2 * dc.n2, db.fft_out);
   DA((size_t)3 * cfg->M, cfg->d_fvals);
-  DA(2, db.flags); DA(2, db.red);
+  DA(2, db.flags); DA(2, db.red); DA(2, db.redb);
+  DA((size_t)4 * dc.K * dc.n1, db.bfft); DA((size_t)4 * dc.K * dc.n1, db.bfft_out);
   (void)hipMemset(db.flags, 0, 2 * sizeof(int));
 #ifdef SK_STAMPS
   DA(8 * 8192, db.stamps);
@@ -807,6 +847,24 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   if (fs != rocfft_status_success) {
     sk_config_destroy(cfg);
     return fail(SK_EHIP, "rocfft_plan_create failed");
+  }
+  {
+    // batched march: even / odd output samples of both rules of every slot
+    if (rocfft_plan_create(&cfg->plan_b, rocfft_placement_notinplace, rocfft_transform_type_complex_inverse,
+                           rocfft_precision_double, 1, len, (size_t)4 * dc.K, nullptr) != rocfft_status_success) {
+      sk_config_destroy(cfg);
+      return fail(SK_EHIP, "rocfft_plan_create (batched march) failed");
+    }
+    size_t wbb = 0;
+    rocfft_plan_get_work_buffer_size(cfg->plan_b, &wbb);
+    rocfft_execution_info_create(&cfg->info_b);
+    if (wbb) {
+      if (hipMalloc(&cfg->fft_work_b, wbb) != hipSuccess) {
+        sk_config_destroy(cfg);
+        return fail(SK_EHIP, "hipMalloc(fft work) failed");
+      }
+      rocfft_execution_info_set_work_buffer(cfg->info_b, cfg->fft_work_b, wbb);
+    }
   }
   {
     // the finufft1d3-level seam (sk_panel_sums) keeps one plain length-n2 transform, in place
@@ -887,6 +945,9 @@ void sk_config_destroy(sk_config* cfg) {
   if (!cfg) return;
   hipSetDevice(cfg->device);
   if (cfg->plan) rocfft_plan_destroy(cfg->plan);
+  if (cfg->plan_b) rocfft_plan_destroy(cfg->plan_b);
+  if (cfg->info_b) rocfft_execution_info_destroy(cfg->info_b);
+  if (cfg->fft_work_b) hipFree(cfg->fft_work_b);
   if (cfg->plan_seam) rocfft_plan_destroy(cfg->plan_seam);
   if (cfg->info_seam) rocfft_execution_info_destroy(cfg->info_seam);
   if (cfg->fft_work_seam) hipFree(cfg->fft_work_seam);
@@ -1272,23 +1333,32 @@ int sk_launch_floor(sk_config* cfg, int reps, double* us4) {
   fin.rhi_for = -1;
   HIPCHK(hipMemcpy(&cfg->db.state[0], &fin, sizeof(fin), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(&cfg->db.state[1], &fin, sizeof(fin), hipMemcpyHostToDevice));
-  // lags of its own: k_interp2 reads xs[min(i, n-1)] ahead of the state, and the last call's array may be gone
+  // lags of its own: the interpolation kernels read xs[min(i, n-1)] ahead of the state (see launch_interp_b), and the
+  // last call's array may be gone
   const long long nfl = 1 << 20;
-  double* d_fl = nullptr;
-  HIPCHK(hipMalloc((void**)&d_fl, nfl * sizeof(double)));
-  HIPCHK(hipMemset(d_fl, 0, nfl * sizeof(double)));
+  struct Scratch {  // released on every path out of this function
+    double* d = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Scratch() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+      if (d) (void)hipFree(d);
+    }
+  } sc;
+  HIPCHK(hipMalloc((void**)&sc.d, nfl * sizeof(double)));
+  HIPCHK(hipMemset(sc.d, 0, nfl * sizeof(double)));
   DevBuffers dbf = cfg->db;
-  dbf.xs = d_fl;
-  hipEvent_t a, b;
-  HIPCHK(hipEventCreate(&a));
-  HIPCHK(hipEventCreate(&b));
-  const unsigned grid = launch_genspread_grid(cfg->dc);
+  dbf.xs = sc.d;
+  HIPCHK(hipEventCreate(&sc.a));
+  HIPCHK(hipEventCreate(&sc.b));
+  hipEvent_t a = sc.a, b = sc.b;
+  const unsigned grid = launch_spread_b_grid(cfg->dc);
   auto bracket = [&](int which, int count) -> double {
     (void)hipEventRecord(a, st);
     for (int q = 0; q < count; ++q) {
       if (which == 0) launch_empty(grid, st);
-      else if (which == 1) launch_genspread(cfg->dc, cfg->d_ec, dbf, SK_MODE_ASIS, 0, nfl, 0.0, 0.0, st);
-      else launch_interp(cfg->dc, cfg->d_ec, dbf, 0, nfl, SK_RAW_NONE, st);
+      else if (which == 1) launch_spread_b(cfg->dc, cfg->d_ec, dbf, SK_MODE_ASIS, 0, nfl, 0.0, 0.0, st);
+      else launch_interp_b(cfg->dc, cfg->d_ec, dbf, 0, nfl, st);
     }
     (void)hipEventRecord(b, st);
     (void)hipEventSynchronize(b);
@@ -1303,9 +1373,6 @@ int sk_launch_floor(sk_config* cfg, int reps, double* us4) {
     us4[which] = sum / reps;
   }
   us4[3] = bracket(0, reps) / reps;
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  (void)hipFree(d_fl);
   HIPCHK(hipGetLastError());
   return SK_OK;
 }

@@ -40,6 +40,9 @@ struct sk_config {
   DevBuffers db;
   std::vector<void*> owned;  // device allocations freed at destroy
   rocfft_plan plan = nullptr;
+  rocfft_plan plan_b = nullptr;     // batched march: 4 K transforms of length n1 (bfft -> bfft_out)
+  rocfft_execution_info info_b = nullptr;
+  void* fft_work_b = nullptr;
   rocfft_plan plan_seam = nullptr;  // sk_panel_sums
   rocfft_execution_info info_seam = nullptr;
   void* fft_work_seam = nullptr;

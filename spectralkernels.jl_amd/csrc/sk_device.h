@@ -92,6 +92,7 @@ struct DevConst {
   // sorted by decreasing source count, so that the dense sub-panel-edge tiles start first
   const int4* tiles[2];
   int ntiles[2];
+  int K;                        // batched march: most panels per step (1, 2, 4 or 8)
 };
 
 // ES-kernel tables (device memory; every workgroup stages them in LDS):
@@ -120,6 +121,34 @@ struct TailScalars {
   int pad;
 };
 
+// Batched steps of the device-resident dim-1 march (catalogue SDFs): one launch triple evaluates up to K panels that
+// the reference would evaluate one after the other PROVIDED each is accepted and none retires a lag -- then they all
+// have the same width M/(2 r_hi) (src/adaptive.jl:152) or are the two children of a rejected panel
+// (src/quadrature.jl:268-270), and share the spread geometry, ES weights, tap positions and 1/phi_hat; only the source
+// strengths and the post-phase differ.  Slot j has centre Cx0 + j dCx and half-width pp.X.
+//   kind 0  the current (sub)panel, plus (kb = 2) its left sibling, which sits on top of the bisection stack;
+//   kind 1  a run of outer panels.  Slot j < kb-1 is only included when the truncation bound of the LARGEST active
+//           lag at pb[j] is still >= tol |k0| / 2: that lag then cannot pass check_convergence (src/adaptive.jl:
+//           231-233), the scan from the top (:183-198) stops at once and no lag retires -- the run is the reference's
+//           schedule, not a guess.
+// The outcome is applied in order by the next step's prologue: the longest accepted prefix v; v == kb, v <= 1 (slot 0's
+// running sums are stored on their own) are applied directly, any other v re-runs the batch capped at v slots.
+constexpr int kBatchMax = 8;
+struct BatchInfo {
+  int kb;              // panels evaluated by this step (1..K)
+  int kind;
+  int last_completes;  // accepting the last slot completes an outer panel: convergence scan + optimistic outputs
+  int force_kb;        // > 0: cap of the next batch (re-run)
+  // the entry this transition pushed on the bisection stack, if any: every workgroup derives the state redundantly but
+  // only one writes the stack, so the others must not read that entry back from memory in the same launch
+  int push_valid, pad_;
+  double push_a, push_b;
+  double Cx0, dCx;     // centre of slot 0, centre step per slot (-2X: siblings, +2X: outer run)
+  double pa[kBatchMax], pb[kBatchMax];  // the reference's bounds of every slot (trace, bisection)
+  TailScalars tail[kBatchMax];          // kind 1: tail fit at pb[j] (src/adaptive.jl:204-229)
+  TailScalars ltail;                    // of the last slot, if it completes an outer panel
+};
+
 struct DevState {
   PanelParams pp;
   double a, b;          // outer panel (src/adaptive.jl:152)
@@ -143,6 +172,9 @@ struct DevState {
   int nan1, nan2;
   long long n_outer, n_panels, n_accepted, sum_active;
   int trace_len;
+  // batched march only (sk_batch_kernels.inc); there conf and pc run over three buffers
+  long long n_steps, n_rerun;   // steps whose outcome was applied / discarded for a capped re-run
+  BatchInfo bt;
 };
 
 // integrand handed to the panel rule (src/quadrature.jl:184-247): S(w) [times w^p log(w) factors as the
@@ -162,6 +194,14 @@ struct Reductions {
   unsigned int hi[64];              // highest lag failing the convergence predicate, +1
   int nan;                          // bit 0: NaN in I1, bit 1: NaN in I2
   int pad[15];
+};
+
+// The same per slot of a batched step.
+struct ReductionsB {
+  unsigned long long max_bits[kBatchMax][64];
+  unsigned int hi[64];              // of the last slot
+  int nan[kBatchMax];               // per slot: bit 0 NaN in I1, bit 1 NaN in I2
+  int pad[8];
 };
 
 // Pinned, host-mapped block through which k_advance reports the state (polled by the host).
@@ -197,6 +237,11 @@ struct DevBuffers {
   double* hk_cheb;          // same shape: Chebyshev coefficients
   // logw first-panel passes (src/quadrature.jl:186-228): raw panel sums A (rules 1, 2) then B (rules 1, 2), n each
   double* lw_raw;
+  // batched march: running sums / outer-panel partial sums over three buffers each (confirmed, after slot 0, after the
+  // last slot), the spread grids of K slots ([slot][rule][even/odd][n1]) and their transforms
+  double* bK[3]; double* bE[3]; double* bP[3];
+  double2* bfft; double2* bfft_out;
+  ReductionsB* redb;        // 2 slots (step parity)
   unsigned long long* stamps;  // diagnostic builds only (SK_STAMPS): 8 words per k_spread workgroup
   unsigned long long* stamps2; // diagnostic builds only: 16 words per k_interp2 workgroup
 };
@@ -204,14 +249,10 @@ struct DevBuffers {
 // launchers (sk_kernels.hip)
 void launch_module_warmup(hipStream_t st);
 void launch_empty(unsigned grid, hipStream_t st);
-unsigned launch_genspread_grid(const DevConst& dc);
 void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t st);  // callback SDFs, dim > 1
 void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0, int g,
                 hipStream_t st);
 void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, hipStream_t st);
-// k_gen + k_spread in one launch (catalogue SDFs, dim 1, device-resident march)
-void launch_genspread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int mode, int t, long long n, double k0,
-                      double ks0, hipStream_t st);
 void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long n, int nu, int raw, hipStream_t st);
 // logw first panel: combine the raw sums of passes A and B with the boundary term (src/quadrature.jl:189,224-225)
 void launch_lw_finish(const DevConst& dc, const DevBuffers& db, int slot, long long n, double B0, hipStream_t st);
@@ -223,6 +264,18 @@ void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& d
 void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, int raw, hipStream_t st);
 void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                     unsigned int seq, hipStream_t st);
+
+// batched march (sk_batch_kernels.inc): node generation + spread of up to dc.K panels / interpolation + epilogue /
+// round boundary
+unsigned launch_spread_b_grid(const DevConst& dc);
+void launch_spread_b(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int mode, int t, long long n, double k0,
+                     double ks0, hipStream_t st);
+// INVARIANT of every interpolation launch (k_interp2, k_interp_b, k_joint_interp): db.xs holds at least n valid doubles.
+// The kernels request xs[min(i, n-1)] and the block's first / last lags AHEAD of the state (to overlap the two round
+// trips), so even a launch whose state says "done" or belongs to another lag set reads them.
+void launch_interp_b(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, hipStream_t st);
+void launch_advance_b(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
+                      unsigned int seq, hipStream_t st);
 
 // joint march (sk_joint_kernels.inc)
 void launch_joint_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const JointSpec& js, const JointBufs& jb,

@@ -49,6 +49,7 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
   JointSpec js;
   std::memset(&js, 0, sizeof(js));
   js.nt = (int)ncfg;
+  int n_logw = 0;
   for (size_t t = 0; t < ncfg; ++t) {
     const sk_config* c = cfgs[t];
     if (!c) return fail(SK_EINVAL, "null config");
@@ -60,6 +61,8 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
         a.has_tail != c0->args.has_tail || (a.has_tail && a.tail != c0->args.tail) || c->dc.w != c0->dc.w)
       return fail(SK_EINVAL, "joint march: quadspec, tol, alpha, convergence_criteria, tail and NUFFT width must agree");
     if (a.logw && a.sdf_dparam) return fail(SK_EUNSUPPORTED, "joint march: logw with a parameter-derivative integrand");
+    // one boundary factor jB0 per march (DevState): a second logw integrand would be given the first one's
+    if (a.logw && n_logw++) return fail(SK_EUNSUPPORTED, "joint march: at most one logw integrand");
     const int ntr_needed = a.logw ? 2 : 1;
     if (js.ntr + ntr_needed > kJointTr) return fail(SK_EINVAL, "joint march: too many raw transforms");
     js.c[t] = c->c;
@@ -103,7 +106,8 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
   const size_t a8 = a256(n * 8);
   const size_t tb = sort_unique_temp_bytes((long long)n);
   const size_t fft_b = a256((size_t)ntr * 4 * n1 * sizeof(double2));
-  const size_t need = 3 * a8 + tb + 512 + (size_t)(8 * nt) * a8 + (size_t)(2 * nt) * a8 + 2 * fft_b + extra_b;
+  // exactly what the pointer bumps below consume
+  const size_t need = extra_b + 3 * a8 + 256 + (a256(tb) + 256) + (size_t)(8 * nt) * a8 + (size_t)(2 * nt) * a8 + 2 * fft_b;
   int rc = ensure_dev_buf(&c0->d_joint, &c0->joint_bytes, need);
   if (rc) return rc;
   char* p = (char*)c0->d_joint;

@@ -2047,38 +2047,6 @@ void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, 
   SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_spread<W, false>), dim3(tiles + 1), dim3(kSpreadThreads), 0, st, dc, ec, db,
                                          slot, 0, 0ll, 0.0, 0.0));
 }
-// workgroups of the fused kernel that are resident at once (so that the state prologue is paid once per slot)
-template <int W>
-static unsigned genspread_resident() {
-  static unsigned cached = 0;
-  if (!cached) {
-    int per_cu = 0, dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_spread<W, true>, kSpreadThreads, 0) != hipSuccess || per_cu < 1)
-      per_cu = 3;
-    cached = (unsigned)(per_cu * cus);
-  }
-  return cached;
-}
-unsigned launch_genspread_grid(const DevConst& dc) {
-  const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
-  unsigned grid = 0;
-  SK_DISPATCH_W(dc.w, {
-    const unsigned res = genspread_resident<W>();
-    grid = tiles + 1 < res ? tiles + 1 : res;
-  });
-  return grid;
-}
-void launch_genspread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int mode, int t, long long n, double k0,
-                      double ks0, hipStream_t st) {
-  const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
-  SK_DISPATCH_W(dc.w, {
-    const unsigned res = genspread_resident<W>();
-    const unsigned grid = tiles + 1 < res ? tiles + 1 : res;  // items are taken with stride gridDim.x
-    hipLaunchKernelGGL((k_spread<W, true>), dim3(grid), dim3(kSpreadThreads), 0, st, dc, ec, db, t, mode, n, k0, ks0);
-  });
-}
 void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, double om, hipStream_t st) {
   // the fixed-geometry spread, all asymptotic terms in one launch
   const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
@@ -2403,5 +2371,6 @@ void launch_gather(const double* ks, const double* errs, const long long* inv, l
 }
 
 #include "sk_joint_kernels.inc"
+#include "sk_batch_kernels.inc"
 
 }  // namespace sk

@@ -13,6 +13,6 @@ def seed27_case(oracle):
     kw = dict(tol=1e-10, quadspec=(128, 8), derivative=True)
     base = oracle.AdaptiveKernelConfig(oracle.SDF.matern(phi, rho, nu, 1), tol=1e-10, quadspec=(128, 8))
     k0 = oracle.compute_k0(base)
-    mk = lambda mod: mod.AdaptiveKernelConfig(mod.SDF.matern(phi, rho, nu, 1), **kw)
+    mk = lambda mod, **extra: mod.AdaptiveKernelConfig(mod.SDF.matern(phi, rho, nu, 1), **kw, **extra)
     truth = oracle.matern_cov_deriv(rs, (phi, rho, nu), d=1)
     return rs, k0, mk, truth

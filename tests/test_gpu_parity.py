@@ -194,7 +194,8 @@ def test_closure_recognition_and_config_helpers(sk, oracle):
     # README-style closures (README.md:26) are recognised as catalogue entries and evaluated on the device: same
     # results as the explicit catalogue config, no host callback per panel; anything else stays a callback
     rs = 10.0 ** np.linspace(-5, 0, 400)
-    auto = sk.AdaptiveKernelConfig(lambda w: (1.0 + w * w) ** -2.0, quadspec=(256, 16))
+    with pytest.warns(UserWarning, match="device catalogue"):  # the reference treats f as a black box: replacing it is announced
+        auto = sk.AdaptiveKernelConfig(lambda w: (1.0 + w * w) ** -2.0, quadspec=(256, 16))
     cat = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5), quadspec=(256, 16))
     assert auto.f.kind == cat.f.kind and auto.f.params == cat.f.params
     a, _ = sk.kernel_values(auto, rs, k0=np.pi / 2)
@@ -202,6 +203,9 @@ def test_closure_recognition_and_config_helpers(sk, oracle):
     assert np.array_equal(a, b) and auto.last_stats()["n_syncs"] == cat.last_stats()["n_syncs"]
     assert sk.recognize_sdf(lambda w: 1.0 / (1.0 + w ** 4)) is None
     assert sk.recognize_sdf(lambda w: (1.0 + w * w) ** -2.0 + 1e-9 * np.exp(-w)) is None
+    # a catalogue form with a cutoff / another tail beyond the first few thousand is NOT the untapered family
+    assert sk.recognize_sdf(lambda w: (1.0 + w * w) ** -2.0 * (w < 5e3)) is None
+    assert sk.recognize_sdf(lambda w: (1.0 + w * w) ** -2.0 if w < 1e6 else (1.0 + w * w) ** -2.5) is None
     assert sk.AdaptiveKernelConfig(lambda w: (1.0 + w * w) ** -2.0, quadspec=(64, 4), sdf="callback").f.kind == 0
     # gen_derivative_config / gen_new_sdf_config (src/adaptive.jl:61-72)
     base = sk.AdaptiveKernelConfig(sk.SDF.matern(2.14, 0.97, 0.89), alpha=0.5, tol=1e-6, quadspec=(256, 16), tail=-2.0,
@@ -493,8 +497,8 @@ def test_stress_seed27_derivative_tol1e10_within_the_oracles_own_spread(sk, orac
     close to the closed form as the oracle is."""
     from seed27 import seed27_case
     rs, k0, mk, truth = seed27_case(oracle)
-    oks, _, otr = oracle.kernel_values(mk(oracle), rs, k0=k0, return_trace=True)
-    oks2, _ = oracle.kernel_values(mk(oracle), rs, k0=k0 * (1 + 1e-4))
+    oks, _, otr = oracle.kernel_values(mk(oracle, nthreads=8), rs, k0=k0, return_trace=True)
+    oks2, _ = oracle.kernel_values(mk(oracle, nthreads=8), rs, k0=k0 * (1 + 1e-4))
     spread = np.abs(oks - oks2).max() / abs(k0)
     cfg = mk(sk)
     ks, errs = sk.kernel_values(cfg, rs, k0=k0)

@@ -275,7 +275,7 @@ def test_derivative_high_accuracy_regime_is_unstable_in_the_oracle_itself(oracle
     rs, k0, mk, truth = seed27_case(oracle)
     res = []
     for eps in (0.0, 1e-4):
-        ks, _, tr = oracle.kernel_values(mk(oracle), rs, k0=k0 * (1 + eps), return_trace=True)
+        ks, _, tr = oracle.kernel_values(mk(oracle, nthreads=8), rs, k0=k0 * (1 + eps), return_trace=True)
         res.append((ks, len(tr)))
     spread = np.abs(res[0][0] - res[1][0]).max() / abs(k0)
     assert res[0][1] != res[1][1]            # another schedule
