@@ -208,6 +208,7 @@ static hipEvent_t ev_get(sk_config* cfg) {
 // GPU fault can be attributed to a kernel (diagnostics only; serialises the pipeline).
 static const bool g_debug_sync = getenv("SK_DEBUG_SYNC") != nullptr;
 static const bool g_no_fuse = getenv("SK_NO_FUSE") != nullptr;  // diagnostics: separate k_gen and k_spread launches
+static const bool g_no_stream = getenv("SK_NO_STREAM") != nullptr;  // diagnostics: rounds with k_advance throughout
 static const char* const k_names[SK_K_COUNT] = {"k_gen", "k_spread", "rocfft", "k_interp", "k_advance"};
 
 // SK_ROCTX=1: roctx ranges named after the reference's @timeit sections (src/adaptive.jl:156-199,
@@ -378,13 +379,14 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
 
   // one evaluation of the current (sub)panel with integrand g and Bessel order nu (dim > 1); raw != 0 stores
   // the panel sums instead of running the epilogue
+  unsigned int stream_seq = 0;  // != 0: streaming phase of the batched march (see below)
   auto eval_pass = [&](int g, int nu, int raw, std::vector<double>& hv) -> int {
     if (cb) {
       int rc = upload_fvals(g, hv);
       if (rc) return rc;
     }
     if (batched) {
-      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread_b(cfg->dc, cfg->d_ec, db, mode, t, n, k0, ks0, st); }
+      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread_b(cfg->dc, cfg->d_ec, db, mode, t, n, k0, ks0, stream_seq, st); }
       {
         EvScope e(cfg, st, SK_K_FFT);
         int rc = run_fft_b(cfg, st);
@@ -512,7 +514,45 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       if (hs->done) break;
       mode = SK_MODE_ASIS;
       R = R < 16 ? 2 * R : 16;
+      if (batched && !g_no_stream) {
+        // ---- streaming phase.  The first step (one or two panels) is all that the quick cases need, and its
+        // k_advance told us so.  From here on no round structure: the host keeps ONE step queued behind the running
+        // one (the spread launch of step t reports t + 1 once it has derived its state) and stops when a spread launch
+        // reports "done" -- at most the rest of that one step is launched in vain, and the device never waits for a
+        // host round trip.
+        stream_seq = ++cfg->seq;
+        volatile unsigned int* prog = &cfg->h_status->progress;
+        volatile unsigned int* dseq = &cfg->h_status->done_seq;
+        *prog = (unsigned int)t;
+        const int depth = 1;  // launched-but-not-started steps: one queued behind the running one
+        unsigned long long spins = 0;
+        for (;;) {
+          while ((unsigned int)t < *prog + (unsigned int)depth && *dseq != stream_seq) {
+            int rc2 = eval_pass(SK_G_DEFAULT, nu_main, SK_RAW_NONE, cfg->h_fvals);
+            if (rc2) return rc2;
+            ++t;
+            mode = SK_MODE_TRANSITION;
+            stt.n_steps_launched++;
+          }
+          if (*dseq == stream_seq) break;
+          if ((++spins & 0x3fff) == 0) {
+            hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess && *dseq != stream_seq && *prog + (unsigned int)depth <= (unsigned int)t)
+              return fail(SK_EHIP, "device finished without reporting progress");
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(SK_EHIP, std::string("HIP error: ") + hipGetErrorString(q));
+          }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        cfg->stats.n_syncs++;
+        if (cfg->h_status->flags[1] & 2) return fail(SK_EHIP, "internal error: inconsistent device state detected by a kernel guard");
+        break;
+      }
     }
+  }
+  if (batched && hs->done > 0 && hs->fix_hi > hs->fix_lo) {
+    // the last retirement happened at slot 0 of a longer batch: outputs from that slot's sums (see k_interp_b)
+    launch_fix_b(cfg->dc, db, hs->fix_lo, hs->fix_hi, hs->fix_conf, hs->fix_tail, st);
+    HIPCHK(hipStreamSynchronize(st));
   }
   HIPCHK(hipGetLastError());
   stt.n_outer = hs->n_outer;
@@ -1357,7 +1397,7 @@ int sk_launch_floor(sk_config* cfg, int reps, double* us4) {
     (void)hipEventRecord(a, st);
     for (int q = 0; q < count; ++q) {
       if (which == 0) launch_empty(grid, st);
-      else if (which == 1) launch_spread_b(cfg->dc, cfg->d_ec, dbf, SK_MODE_ASIS, 0, nfl, 0.0, 0.0, st);
+      else if (which == 1) launch_spread_b(cfg->dc, cfg->d_ec, dbf, SK_MODE_ASIS, 0, nfl, 0.0, 0.0, 0u, st);
       else launch_interp_b(cfg->dc, cfg->d_ec, dbf, 0, nfl, st);
     }
     (void)hipEventRecord(b, st);

@@ -127,17 +127,20 @@ struct TailScalars {
 // (src/quadrature.jl:268-270), and share the spread geometry, ES weights, tap positions and 1/phi_hat; only the source
 // strengths and the post-phase differ.  Slot j has centre Cx0 + j dCx and half-width pp.X.
 //   kind 0  the current (sub)panel, plus (kb = 2) its left sibling, which sits on top of the bisection stack;
-//   kind 1  a run of outer panels.  Slot j < kb-1 is only included when the truncation bound of the LARGEST active
-//           lag at pb[j] is still >= tol |k0| / 2: that lag then cannot pass check_convergence (src/adaptive.jl:
-//           231-233), the scan from the top (:183-198) stops at once and no lag retires -- the run is the reference's
-//           schedule, not a guess.
-// The outcome is applied in order by the next step's prologue: the longest accepted prefix v; v == kb, v <= 1 (slot 0's
-// running sums are stored on their own) are applied directly, any other v re-runs the batch capped at v slots.
+//   kind 1  a run of outer panels.  Slot j+1 follows slot j in the reference iff slot j is accepted and retires no
+//           lag.  That is CERTAIN while the truncation bound of the largest active lag at pb[j] is >= tol |k0| / 2
+//           (the lag fails check_convergence, src/adaptive.jl:231-233, so the scan from the top, :183-198, stops at
+//           once); beyond that it is a guess, made while the previous outer panel retired nothing (spec_ok) and
+//           checked afterwards from slot j's own convergence scan.
+// The outcome is applied in order by the next step's prologue: the longest prefix v of slots that the reference would
+// have evaluated.  The running sums are stored after slot 0 and after the last slot, so v == kb and v <= 1 are applied
+// directly and any other v re-runs the batch capped at v slots.  Lags that retire at slot 0 of a longer batch take
+// their outputs from slot 0's sums in the next launch (fix_*).
 constexpr int kBatchMax = 8;
 struct BatchInfo {
   int kb;              // panels evaluated by this step (1..K)
   int kind;
-  int last_completes;  // accepting the last slot completes an outer panel: convergence scan + optimistic outputs
+  int cmask;           // bit j: accepting slot j completes an outer panel (convergence scan with tail[j])
   int force_kb;        // > 0: cap of the next batch (re-run)
   // the entry this transition pushed on the bisection stack, if any: every workgroup derives the state redundantly but
   // only one writes the stack, so the others must not read that entry back from memory in the same launch
@@ -145,8 +148,9 @@ struct BatchInfo {
   double push_a, push_b;
   double Cx0, dCx;     // centre of slot 0, centre step per slot (-2X: siblings, +2X: outer run)
   double pa[kBatchMax], pb[kBatchMax];  // the reference's bounds of every slot (trace, bisection)
-  TailScalars tail[kBatchMax];          // kind 1: tail fit at pb[j] (src/adaptive.jl:204-229)
-  TailScalars ltail;                    // of the last slot, if it completes an outer panel
+  TailScalars tail[kBatchMax];          // of the outer panel that slot j completes (src/adaptive.jl:204-229)
+  double g[kBatchMax + 1];              // outer run: |w^p S(w)| at pa[0], pb[0], pb[1], ...: size of a panel's
+                                        // contribution at the largest lag (batch_build's guess)
 };
 
 struct DevState {
@@ -174,6 +178,9 @@ struct DevState {
   int trace_len;
   // batched march only (sk_batch_kernels.inc); there conf and pc run over three buffers
   long long n_steps, n_rerun;   // steps whose outcome was applied / discarded for a capped re-run
+  int spec_ok, fix_conf;        // the last completed outer panel retired nothing; buffer of the pending output fix
+  long long fix_lo, fix_hi;     // lags [fix_lo, fix_hi) retired at slot 0 of a longer batch: outputs = sums in fix_conf
+  TailScalars fix_tail;         //   + 2 x the truncation bound of that slot (src/adaptive.jl:194)
   BatchInfo bt;
 };
 
@@ -199,7 +206,7 @@ struct Reductions {
 // The same per slot of a batched step.
 struct ReductionsB {
   unsigned long long max_bits[kBatchMax][64];
-  unsigned int hi[64];              // of the last slot
+  unsigned int hi[kBatchMax][64];   // highest lag failing the convergence predicate of slot j, +1
   int nan[kBatchMax];               // per slot: bit 0 NaN in I1, bit 1 NaN in I2
   int pad[8];
 };
@@ -211,6 +218,10 @@ struct HostStatus {
   // Hankel path: number of active lags with r <= r_hi / kHkBeta^l, l = 0..kHkMaxLevels (level planning on the host)
   long long lvl_cnt[kHkMaxLevels + 1];
   unsigned int seq;
+  // streaming phase of the batched march (no k_advance): the spread launch of step t stores t + 1 in `progress` once it
+  // has derived state_t, and when that state says "done" copies it into `state` and stores the call's tag in `done_seq`
+  unsigned int progress;
+  unsigned int done_seq;
 };
 
 struct DevBuffers {
@@ -269,13 +280,15 @@ void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, l
 // round boundary
 unsigned launch_spread_b_grid(const DevConst& dc);
 void launch_spread_b(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int mode, int t, long long n, double k0,
-                     double ks0, hipStream_t st);
+                     double ks0, unsigned int stream_seq, hipStream_t st);
 // INVARIANT of every interpolation launch (k_interp2, k_interp_b, k_joint_interp): db.xs holds at least n valid doubles.
 // The kernels request xs[min(i, n-1)] and the block's first / last lags AHEAD of the state (to overlap the two round
 // trips), so even a launch whose state says "done" or belongs to another lag set reads them.
 void launch_interp_b(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, hipStream_t st);
 void launch_advance_b(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                       unsigned int seq, hipStream_t st);
+// outputs of lags [lo, hi) from the running sums in buffer `conf` (a march that ended with a pending fix)
+void launch_fix_b(const DevConst& dc, const DevBuffers& db, long long lo, long long hi, int conf, TailScalars tail, hipStream_t st);
 
 // joint march (sk_joint_kernels.inc)
 void launch_joint_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const JointSpec& js, const JointBufs& jb,

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include "sk_device.h"
+#include "sk_lean_math.h"
 #include "../../include/spectralkernels_hip.h"
 
 namespace sk {
@@ -2026,6 +2027,13 @@ void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, l
   hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, dc, db, mode, t, n, k0, ks0, seq);
 }
 
+#ifdef SK_DEV_FAST  // development builds: two kernel widths only (compile time)
+#define SK_DISPATCH_W(w, CALL) \
+  switch (w) {                 \
+    case 12: { constexpr int W = 12; CALL; } break; \
+    default: { constexpr int W = 16; CALL; } break; \
+  }
+#else
 #define SK_DISPATCH_W(w, CALL) \
   switch (w) {                 \
     case 4: { constexpr int W = 4; CALL; } break;   \
@@ -2036,6 +2044,7 @@ void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, l
     case 14: { constexpr int W = 14; CALL; } break; \
     default: { constexpr int W = 16; CALL; } break; \
   }
+#endif
 
 void launch_gen(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0, int g,
                 hipStream_t st) {
