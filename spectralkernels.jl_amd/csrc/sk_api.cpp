@@ -209,6 +209,7 @@ static hipEvent_t ev_get(sk_config* cfg) {
 static const bool g_debug_sync = getenv("SK_DEBUG_SYNC") != nullptr;
 static const bool g_no_fuse = getenv("SK_NO_FUSE") != nullptr;  // diagnostics: separate k_gen and k_spread launches
 static const bool g_no_stream = getenv("SK_NO_STREAM") != nullptr;  // diagnostics: rounds with k_advance throughout
+static const bool g_debug_batch = getenv("SK_DEBUG_BATCH") != nullptr;  // diagnostics: one step per round, every state printed
 static const char* const k_names[SK_K_COUNT] = {"k_gen", "k_spread", "rocfft", "k_interp", "k_advance"};
 
 // SK_ROCTX=1: roctx ranges named after the reference's @timeit sections (src/adaptive.jl:156-199,
@@ -511,10 +512,18 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       if (rc) return rc;
       if (cfg->h_status->flags[1] & 2) return fail(SK_EHIP, "internal error: inconsistent device state detected by a kernel guard");
       if (check_flags && (cfg->h_status->flags[0] || cfg->h_status->flags[1])) return SK_OK;
+      if (batched && g_debug_batch) {
+        const BatchInfo& bi = hs->bt;
+        fprintf(stderr, "[sk] t=%d done=%d hi=%lld kb=%d kind=%d cmask=%d spec_ok=%d pending=%d force=%d conf=%d stack=%d "
+                        "panel [%.9g, %.9g] slots:", t, hs->done, hs->hi, bi.kb, bi.kind, bi.cmask, hs->spec_ok, bi.tails_pending,
+                bi.force_kb, hs->conf, hs->stack_len, hs->pp.pa, hs->pp.pb);
+        for (int q = 0; q < bi.kb; ++q) fprintf(stderr, " [%.9g,%.9g t1=%.3e t2=%.3e c=%d]", bi.pa[q], bi.pb[q], bi.tail[q].t1, bi.tail[q].t2num, bi.tail[q].crit);
+        fprintf(stderr, " fix[%lld,%lld) n_panels=%lld\n", hs->fix_lo, hs->fix_hi, hs->n_panels);
+      }
       if (hs->done) break;
       mode = SK_MODE_ASIS;
-      R = R < 16 ? 2 * R : 16;
-      if (batched && !g_no_stream) {
+      R = g_debug_batch ? 1 : (R < 16 ? 2 * R : 16);
+      if (batched && !g_no_stream && !g_debug_batch) {
         // ---- streaming phase.  The first step (one or two panels) is all that the quick cases need, and its
         // k_advance told us so.  From here on no round structure: the host keeps ONE step queued behind the running
         // one (the spread launch of step t reports t + 1 once it has derived its state) and stops when a spread launch

@@ -144,7 +144,8 @@ struct BatchInfo {
   int force_kb;        // > 0: cap of the next batch (re-run)
   // the entry this transition pushed on the bisection stack, if any: every workgroup derives the state redundantly but
   // only one writes the stack, so the others must not read that entry back from memory in the same launch
-  int push_valid, pad_;
+  int push_valid;
+  int tails_pending;   // the tail fits of this batch's slots are left to the end of the spread launch (off the critical path)
   double push_a, push_b;
   double Cx0, dCx;     // centre of slot 0, centre step per slot (-2X: siblings, +2X: outer run)
   double pa[kBatchMax], pb[kBatchMax];  // the reference's bounds of every slot (trace, bisection)

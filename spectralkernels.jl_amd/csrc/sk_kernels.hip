@@ -2088,8 +2088,8 @@ void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, 
   } else if (g_interp_variant == 1) {
     SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp<W, SK_RAW_NONE>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
   } else {
-    // 7 waves per SIMD up to W = 12; the wider kernels need a few registers more (6 waves: no spills)
-    SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp2<W, (W >= 14 ? 6 : 7)>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
+    // 7 waves per SIMD up to W = 12; the wider kernels need more registers (5 waves: no spills, tests/test_code_object.py)
+    SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_interp2<W, (W == 14 ? 4 : (W == 16 ? 6 : 7))>), dim3(g), dim3(256), 0, st, dc, ec, db, slot, n));
   }
 }
 
