@@ -4,10 +4,13 @@
 One "step" = one kernel_values pass over one batch of synthetic lags: BASELINE config 2 by default -- Matern
 nu=3/2 SDF S(w) = (1+w^2)^-2, 10^6 log-spaced r in [1e-6, 1], tol = 1e-8, quadspec (4096, 16).
 
-  value         lags already resident in HBM when the timed region starts (sk_kernel_values_device)
-  host_to_host  the reference-shaped call (src/adaptive.jl:95-108: host Vector in, two host Vectors out) on the
-                same lags through sk_kernel_values: sorted, permuted with duplicates, and from pinned arrays --
-                SURVEY 8(d)'s "host entry -> results in host memory" span; cpu_baseline is quoted against it
+  value         span "device_resident": lags already in HBM when the timed region starts (sk_kernel_values_device),
+                results left in HBM -- the contract's `value`
+  host_to_host  span "host_to_host" (host entry -> results in host memory): the reference-shaped call
+                (src/adaptive.jl:95-108: host Vector in, two FRESH host Vectors out) on the same lags through
+                sk_kernel_values; headline leg = fresh result vectors as the API hands them out (pinned pool), then
+                fresh pageable vectors, reused vectors, permuted input with duplicates, everything pinned;
+                cpu_baseline is quoted against it
 
 Multi-GPU: one process per GPU (torch.distributed over RCCL); every rank marches its own 10^6-lag shard of the
 r-set (weak scaling, no data-path collective); the only exchange is the K(0) normaliser, whose quadrature is split
@@ -30,7 +33,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-ROUND = "r02"
+ROUND = "r03"
 
 WORKLOADS = {
     # name: (sdf kind, params, config kwargs, r-grid builder, k0, truth)
@@ -96,6 +99,17 @@ def reference_probe():
         found["python_finufft"] = False
     ok = bool(found["julia"]) or bool(found["libfinufft"]) or found["python_finufft"]
     return ("available" if ok else "unavailable"), found
+
+
+def kernels_sha():
+    """Identity of the kernel sources a PMC / instruction-mix summary under profiles/ belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "spectralkernels.jl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".inc", ".h", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def timed(fn, steps, warmup, fence):
@@ -216,10 +230,10 @@ def main():
         legs = {}
         io_bytes = 24.0 * n
 
-        def leg(name, xs, into=None):
+        def leg(name, xs, into=None, results="pinned"):
             out = {}
-            if into is None:  # fresh result arrays every call, as the reference's kernel_values returns them
-                fn = lambda: out.__setitem__("r", sk.kernel_values(cfg, xs, k0=k0))
+            if into is None:  # fresh result vectors every call, as the reference's kernel_values returns them
+                fn = lambda: out.__setitem__("r", sk.kernel_values(cfg, xs, k0=k0, results=results))
             else:             # caller-provided result arrays (the C ABI's contract), reused across calls
                 fn = lambda: out.__setitem__("r", sk.kernel_values_into(cfg, xs, k0, into[0], into[1]))
             dth = timed(fn, hsteps, hwarm, nofence) / hsteps
@@ -228,9 +242,12 @@ def main():
                           "split_ms": {k: round(v, 4) for k, v in tm.items()}, "unique_lags": cfg.last_stats()["n_unique"]}
             return out["r"]
 
-        hv, _ = leg("sorted", rs, into=(np.empty(n), np.empty(n)))
-        host_err = float(np.abs(hv - ks).max() / abs(k0))
-        leg("sorted_fresh_result_arrays", rs)
+        # the reference's contract first: sorted pageable lags in, two fresh vectors out (from the API's pinned pool)
+        hv, _ = leg("fresh_result_vectors", rs)
+        host_err = float(np.abs(np.asarray(hv) - ks).max() / abs(k0))
+        del hv
+        leg("fresh_pageable_result_vectors", rs, results="pageable")
+        leg("reused_result_vectors", rs, into=(np.empty(n), np.empty(n)))
         prng = np.random.default_rng(7)
         perm = prng.permutation(n)
         xs_p = np.ascontiguousarray(np.r_[rs[perm[: n - n // 10]], rs[perm[: n // 10]]])  # 10 % duplicates, shuffled
@@ -239,12 +256,15 @@ def main():
         truth_p = k0 * (1 + 2 * np.pi * xs_p) * np.exp(-2 * np.pi * xs_p) if args.workload == "C2" else None
         px, pk, pe = sk.pinned_empty(n), sk.pinned_empty(n), sk.pinned_empty(n)
         px[:] = rs
-        leg("sorted_pinned_arrays", px, into=(pk, pe))
-        host = {"what": "sk_kernel_values: pageable host array in, two pageable host arrays out (src/adaptive.jl:95-108), "
-                        "%d steps; legs: result arrays reused / fresh per call / permuted input with duplicates / "
-                        "all three arrays in pinned memory (sk_host_alloc)" % hsteps,
-                "ms_per_step": legs["sorted"]["ms_per_step"], "value": legs["sorted"]["value"], "unit": "r-targets/s",
-                "GB/s_effective": legs["sorted"]["GB/s_effective"], "legs": legs,
+        leg("all_pinned_arrays", px, into=(pk, pe))
+        head = legs["fresh_result_vectors"]
+        host = {"span": "host_to_host",
+                "what": "sk_kernel_values: pageable host array in, two host arrays out (src/adaptive.jl:95-108), %d steps.  "
+                        "Headline = fresh_result_vectors: the two result vectors are new per call, as the reference returns "
+                        "them, and come from the API's pool of pinned vectors; other legs: fresh pageable vectors / "
+                        "caller-provided reused vectors / permuted input with duplicates / all three arrays pinned" % hsteps,
+                "ms_per_step": head["ms_per_step"], "value": head["value"], "unit": "r-targets/s",
+                "GB/s_effective": head["GB/s_effective"], "legs": legs,
                 "max_abs_diff_vs_device_leg_over_k0": host_err,
                 "permuted_max_rel_err_vs_closed_form": (float(np.abs(pv - truth_p).max() / abs(k0))
                                                         if truth_p is not None else None),
@@ -265,14 +285,20 @@ def main():
                     acc[k][f] += kt[k][f]
     cfg.profile(False)
     st = cfg.last_stats()
-    # dominant kernel: k_interp (largest share of device time in the rocprofv3 kernel stats, profiles/*_summary.txt;
-    # the HIP-event brackets add the launch gap to whichever kernel follows a host synchronisation, so the event
-    # totals of k_interp and the fused k_spread are too close to rank them reliably)
+    # dominant kernel: the interpolation launch (largest share of device time in the rocprofv3 kernel stats,
+    # profiles/*_summary.txt; the HIP-event brackets add the launch gap to whichever kernel follows a host
+    # synchronisation, so the event totals of interpolation and spread are too close to rank them reliably)
     dom = "interp" if acc.get("interp", {}).get("launches", 0) > 0 else max(acc, key=lambda k: acc[k]["total_ms"])
+    batched = w["kw"].get("dim", 1) == 1
+    dom_name = "k_interp_b" if (dom == "interp" and batched) else ("k_hk_interp" if dom == "interp" else "k_" + dom)
     M = cfg.quadspec[0] * cfg.quadspec[1]
-    # interp per active lag and evaluation: read r (8) + confirmed sums (16, not on the very first panel), write the
-    # optimistic sums (16); the final outputs (16) once per lag, when it retires  -> 40 B x sum_active per call
-    interp_bytes_total = 10 * 40.0 * st["sum_active"]  # over the 10 profiled calls
+    n1 = M  # spread grid of this geometry; the batched FFT plan transforms 4 K grids of n1
+    # interpolation, per STEP (a step evaluates one or more panels of equal width) and active lag: read r (8) and the
+    # confirmed sums (16, not on the very first step), write the sums after the step (16) = 40 B; the final outputs (16)
+    # once per lag, when it retires.  The batched kernel also stores the sums after the step's FIRST panel (16 B more
+    # when a step has several panels): overhead, counted in `traffic`, not here.
+    interp_bytes_total = 10 * (40.0 * st["sum_active_steps"] + 16.0 * st["n_unique"])  # over the 10 profiled calls
+    panels_per_step = st["n_panels"] / max(1, st["n_steps"])
     rl = {}
     for k, v in acc.items():
         if v["launches"] == 0:
@@ -284,32 +310,31 @@ def main():
         elif k == "gen":
             b = 48.0 * M + 48.0 * M  # read node + weight of both rules (M + 2M) x (8 + 8), write 3M complex strengths
         elif k == "spread":
-            # read 3M complex strengths (separate k_gen) or 3M nodes + weights (fused launch) and 3M positions;
-            # write two complex grids
-            b = 48.0 * M + 24.0 * M + 16.0 * items
+            # read 3M source positions + Gauss weights (the strengths are computed while staging) and the tile list;
+            # write, per panel of the step, the even / odd grids of both rules: 4 n1 complex
+            b = (24.0 * 2 * M + 4 * 16.0 * n1 * panels_per_step) if batched else (48.0 * M + 24.0 * M + 16.0 * items)
         elif k == "fft":
-            b = 2 * 16.0 * items  # read + write both grids once
+            b = 2 * 16.0 * items  # read + write the grids once
         else:
             b = 0.0
         rl[k] = dict(avg_us=1e3 * avg_ms, bytes=b, gbps=(b / (avg_ms * 1e-3) / 1e9) if avg_ms > 0 else 0.0,
                      launches_per_step=v["launches"] / 10.0)
     peak = 8000.0
-    # HBM bytes per launch of the dominant kernel from the committed PMC summary of this round
-    # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/profile_round.sh)
-    traffic = None
-    for rnd in (ROUND, "r01"):
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "%s_%s_summary.json" % (rnd, args.workload.lower()))))
+    # HBM bytes per launch of the dominant kernel from the PMC summary of this round -- only if that summary was taken
+    # from THESE kernel sources (kernels_sha) and names this kernel; a stale number is worse than none
+    traffic, traffic_src = None, None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "%s_%s_summary.json" % (ROUND, args.workload.lower()))))
+        if pj.get("kernels_sha") == kernels_sha():
             for kname, tv in pj.get("traffic", {}).items():
-                if ("k_" + dom) in kname:
+                if dom_name in kname:
                     traffic = tv["hbm_bytes_per_launch"]
-            if traffic is not None:
-                break
-        except Exception:
-            pass
+                    traffic_src = "profiles/%s_%s_summary.json (rocprofv3 --pmc, same kernel sources)" % (ROUND, args.workload.lower())
+    except Exception:
+        pass
     floor = {} if args.no_launch_floor else cfg.launch_floor()
-    roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": rl[dom]["gbps"], "peak": peak, "unit": "GB/s",
-                "frac": rl[dom]["gbps"] / peak, "traffic": traffic, "avg_us": rl[dom]["avg_us"],
+    roofline = {"kernel": dom_name, "bound": "hbm", "achieved": rl[dom]["gbps"], "peak": peak, "unit": "GB/s",
+                "frac": rl[dom]["gbps"] / peak, "traffic": traffic, "traffic_source": traffic_src, "avg_us": rl[dom]["avg_us"],
                 "algorithmic_bytes_per_launch": rl[dom]["bytes"],
                 "per_kernel": {k: {"avg_us": round(v["avg_us"], 3), "GB/s": round(v["gbps"], 1),
                                    "launches_per_step": v["launches_per_step"]} for k, v in rl.items()},
@@ -319,11 +344,16 @@ def main():
                 "launch_floor_us": floor}
     if "spread" in roofline["per_kernel"]:
         roofline["per_kernel"]["spread"]["launch_floor_us"] = floor.get("spread_prologue_only")
+        # north_star: ">= 40 % of the HBM roofline in the NUFFT spread step"
+        roofline["per_kernel"]["spread"]["frac"] = round(rl["spread"]["gbps"] / peak, 4)
+        roofline["per_kernel"]["spread"]["target_frac"] = 0.40
+        roofline["per_kernel"]["spread"]["panels_per_launch"] = round(panels_per_step, 3)
     # the dominant kernel's other roofline: vector-instruction issue.  Dynamic instructions per wave from the committed
     # PMC passes (profiles/r02_interp_instmix.json), one wave instruction per SIMD every 4 cycles, 1024 SIMDs at the
     # 2.4 GHz peak clock -- the bound that explains why the kernel sits at a fifth of the HBM peak
     try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "%s_interp_instmix.json" % ROUND))).get(str(cfg.nufft_width))
+        mixj = json.load(open(os.path.join(ROOT, "profiles", "%s_interp_instmix.json" % ROUND)))
+        mix = mixj.get(str(cfg.nufft_width)) if mixj.get("kernels_sha") == kernels_sha() else None
         if dom == "interp" and mix:
             waves = 4.0 * (acc["interp"]["active_items"] / acc["interp"]["launches"]) / 256.0
             issue_us = waves * mix["valu_per_wave"] * 4.0 / (1024 * 2.4e3)
@@ -334,7 +364,7 @@ def main():
         pass
     # whole-step view: algorithmic bytes per lag (24 + 40*abar + 48*M*Q/N) over the step time
     abar = st["sum_active"] / max(1, st["n_unique"])
-    bytes_per_lag = 24.0 + 40.0 * abar + 48.0 * M * st["n_panels"] / max(1, n)
+    bytes_per_lag = 24.0 + 40.0 * abar + 48.0 * M * st["n_panels"] / max(1, n)  # SURVEY 8(d), per panel evaluation
     roofline["step_GB/s"] = bytes_per_lag * n / (1e3 * dt_local / args.steps * 1e-3) / 1e9
     roofline["step_frac"] = roofline["step_GB/s"] / peak
     roofline["bytes_per_lag"] = bytes_per_lag
@@ -397,13 +427,13 @@ def main():
         out = {"metric": "r-targets/sec at tol=%g" % w["kw"]["tol"], "value": value, "unit": "r-targets/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                "scaling": "strong" if args.workload == "C4" and world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
-               "data": "synthetic",
+               "data": "synthetic", "span": "device_resident",
                "config": {"workload": args.workload + ": " + w["desc"], "lags_per_gpu": n,
                           "sharding": "r-set %s over ranks, K(0) all-reduce at set-up only" % args.shard,
                           "nufft_width": cfg.nufft_width},
                "max_rel_err_vs_closed_form": max_rel_err,
-               "panels": {"outer": st["n_outer"], "nufft_pairs": st["n_panels"], "abar": abar,
-                          "steps_launched": st["n_steps_launched"], "host_syncs": st["n_syncs"]},
+               "panels": {"outer": st["n_outer"], "nufft_pairs": st["n_panels"], "abar": abar, "steps": st["n_steps"],
+                          "steps_rerun": st["n_rerun"], "steps_launched": st["n_steps_launched"], "host_syncs": st["n_syncs"]},
                "rccl_ranks": world if (dist is not None and args.backend == "nccl") else 0, "per_rank": per_rank,
                "host_to_host": host, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))

@@ -114,6 +114,7 @@ typedef struct {
   double last_b;         /* upper end of the last panel */
   int64_t n_steps;       /* device steps whose panels were applied (a step evaluates 1..batch_panels panels) */
   int64_t n_rerun;       /* steps discarded and re-run with fewer panels (a later panel of the batch was rejected) */
+  int64_t sum_active_steps; /* sum over applied steps of active targets: each step reads and writes a lag's sums once */
 } sk_stats;
 int sk_last_stats(const sk_config* cfg, sk_stats* out);
 
@@ -265,6 +266,11 @@ int sk_host_es_eval(int w, double z, double* phi, double* phi_poly);
  * the same pass -- src/adaptive.jl:99,113) on plain memory: stage receives the copy; *order = 1 strictly increasing,
  * 2 not, 3 a negative / NaN lag.  threads <= 0: the library's default (SK_COPY_THREADS). */
 int sk_host_stage_scan(const double* src, size_t cnt, double* stage, int threads, int* order);
+
+/* Layout of the structs that cross this boundary, for bindings that mirror them by hand (the Julia shim, ctypes):
+ * which = 0 sk_config_args, 1 sk_stats, 2 sk_kernel_times.  out receives sizeof(struct) followed by the byte offset of
+ * every field in declaration order (at most cap entries); *len = number of entries of the full description. */
+int sk_abi_layout(int which, size_t* out, size_t cap, size_t* len);
 
 const char* sk_last_error(void);
 const char* sk_version(void);

@@ -26,7 +26,8 @@ class ConfigArgs(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_unique", C.c_int64), ("n_outer", C.c_int64), ("n_panels", C.c_int64), ("n_accepted", C.c_int64),
                 ("sum_active", C.c_int64), ("n_steps_launched", C.c_int64), ("n_syncs", C.c_int64),
-                ("last_b", C.c_double), ("n_steps", C.c_int64), ("n_rerun", C.c_int64)]
+                ("last_b", C.c_double), ("n_steps", C.c_int64), ("n_rerun", C.c_int64),
+                ("sum_active_steps", C.c_int64)]
 
 
 K_NAMES = ["gen", "spread", "fft", "interp", "advance"]
@@ -96,11 +97,28 @@ def load():
     L.sk_host_compute_k0_part.argtypes = [C.POINTER(ConfigArgs), C.c_double, C.c_double, dp]
     L.sk_host_validate.argtypes = [C.POINTER(ConfigArgs), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sk_host_es_eval.argtypes = [C.c_int, C.c_double, dp, dp]
+    L.sk_abi_layout.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sk_host_stage_scan.argtypes = [vp, C.c_size_t, vp, C.c_int, C.POINTER(C.c_int)]
     L.sk_last_error.restype = C.c_char_p
     L.sk_version.restype = C.c_char_p
     L.sk_device_available.restype = C.c_int
     _lib = L
     return L
+
+
+def abi_layout(which):
+    """[sizeof, offset of every field] of struct `which` (0 sk_config_args, 1 sk_stats, 2 sk_kernel_times) as the library
+    was compiled (sk_abi_layout)."""
+    out = (C.c_size_t * 64)()
+    n = C.c_size_t()
+    if load().sk_abi_layout(which, out, 64, C.byref(n)) != 0:
+        raise RuntimeError(last_error())
+    return [int(out[i]) for i in range(n.value)]
+
+
+def mirror_layout(cls):
+    """The same description of a ctypes mirror."""
+    return [C.sizeof(cls)] + [getattr(cls, name).offset for name, _ in cls._fields_]
 
 
 def last_error():

@@ -61,3 +61,14 @@ def build_stamps(verbose=False):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return out
+
+
+def build_variant(flags, name="libsk_var.so", verbose=False):
+    """Diagnostic build with extra -D flags for same-box A/B runs (tools/diag/ab_libs.sh): tools/diag/<name>."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(os.path.dirname(HERE), "tools", "diag", name)
+    cmd = [hipcc] + FLAGS + list(flags) + ["-shared", "-o", out] + [os.path.join(CSRC, f) for f in SOURCES] + ["-lrocfft"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out

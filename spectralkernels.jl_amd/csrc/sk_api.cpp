@@ -571,6 +571,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   stt.last_b = hs->b;
   stt.n_steps = batched ? hs->n_steps : hs->n_panels;
   stt.n_rerun = batched ? hs->n_rerun : 0;
+  stt.sum_active_steps = batched ? hs->sum_active_steps : hs->sum_active;
   cfg->trace_len = (size_t)hs->trace_len;
   cfg->trace_valid = false;
   if (cfg->profile) {
@@ -1465,6 +1466,35 @@ int sk_last_trace(const sk_config* cfg_c, double* rec, size_t cap, size_t* len) 
     rec[5 * i + 4] = r.accepted;
   }
   *len = nrec;
+  return SK_OK;
+}
+
+int sk_abi_layout(int which, size_t* out, size_t cap, size_t* len) {
+  if (!out || !len) return fail(SK_EINVAL, "null argument");
+  std::vector<size_t> v;
+#define F(T, f) v.push_back(offsetof(T, f))
+  if (which == 0) {
+    v.push_back(sizeof(sk_config_args));
+    F(sk_config_args, sdf_kind); F(sk_config_args, sdf_params); F(sk_config_args, f); F(sk_config_args, f_ctx);
+    F(sk_config_args, df); F(sk_config_args, df_ctx); F(sk_config_args, dim); F(sk_config_args, alpha);
+    F(sk_config_args, tol); F(sk_config_args, derivative); F(sk_config_args, logw); F(sk_config_args, criteria);
+    F(sk_config_args, has_tail); F(sk_config_args, tail); F(sk_config_args, m); F(sk_config_args, k);
+    F(sk_config_args, device); F(sk_config_args, nufft_width); F(sk_config_args, hankel_min_lags);
+    F(sk_config_args, sdf_dparam); F(sk_config_args, batch_panels);
+  } else if (which == 1) {
+    v.push_back(sizeof(sk_stats));
+    F(sk_stats, n_unique); F(sk_stats, n_outer); F(sk_stats, n_panels); F(sk_stats, n_accepted); F(sk_stats, sum_active);
+    F(sk_stats, n_steps_launched); F(sk_stats, n_syncs); F(sk_stats, last_b); F(sk_stats, n_steps); F(sk_stats, n_rerun);
+    F(sk_stats, sum_active_steps);
+  } else if (which == 2) {
+    v.push_back(sizeof(sk_kernel_times));
+    F(sk_kernel_times, total_ms); F(sk_kernel_times, launches); F(sk_kernel_times, active_items);
+  } else {
+    return fail(SK_EINVAL, "sk_abi_layout: which must be 0, 1 or 2");
+  }
+#undef F
+  *len = v.size();
+  for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
   return SK_OK;
 }
 

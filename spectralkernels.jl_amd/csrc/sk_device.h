@@ -179,6 +179,7 @@ struct DevState {
   int trace_len;
   // batched march only (sk_batch_kernels.inc); there conf and pc run over three buffers
   long long n_steps, n_rerun;   // steps whose outcome was applied / discarded for a capped re-run
+  long long sum_active_steps;   // sum over applied steps of active lags
   int spec_ok, fix_conf;        // the last completed outer panel retired nothing; buffer of the pending output fix
   long long fix_lo, fix_hi;     // lags [fix_lo, fix_hi) retired at slot 0 of a longer batch: outputs = sums in fix_conf
   TailScalars fix_tail;         //   + 2 x the truncation bound of that slot (src/adaptive.jl:194)

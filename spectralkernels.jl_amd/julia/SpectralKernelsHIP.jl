@@ -10,8 +10,8 @@
 module SpectralKernelsHIP
 
 export AdaptiveKernelConfig, kernel_values, kernel_values!, kernel_values_multi, kernel_values_joint, kernel_values_pairs,
-       build_dense_cov_matrix, compute_k0, gen_derivative_config, gen_new_sdf_config, recognize_sdf, pinned_vector,
-       ShardedKernelConfig, MaternSDF, ExponentialSDF, GaussianSDF, sdf_derivative
+       kernel_jacobian_pairs, build_dense_cov_matrix, compute_k0, gen_derivative_config, gen_new_sdf_config, recognize_sdf,
+       pinned_vector, ShardedKernelConfig, MaternSDF, ExponentialSDF, GaussianSDF, sdf_derivative, check_abi
 
 const LIB = get(ENV, "SPECTRALKERNELS_HIP_LIB",
                 joinpath(@__DIR__, "..", "libspectralkernels_hip.so"))
@@ -36,16 +36,18 @@ sdf_derivative(s::MaternSDF, j::Integer)      = MaternSDF(s.phi, s.rho, s.nu, s.
 sdf_derivative(s::ExponentialSDF, j::Integer) = ExponentialSDF(s.a, j)
 sdf_derivative(s::GaussianSDF, j::Integer)    = GaussianSDF(s.a, j)
 
-const PROBES = [0.0, 1e-3, 0.017, 0.13, 0.71, 1.0, 2.3, 9.1, 47.0, 3.1e2, 2.2e3]
+# the first eleven solve for / verify the parameters; the rest reach into the range a march visits, so that a closure
+# with a cutoff or another tail beyond a few thousand is not taken for the untapered family
+const PROBES = [0.0, 1e-3, 0.017, 0.13, 0.71, 1.0, 2.3, 9.1, 47.0, 3.1e2, 2.2e3, 1.7e4, 1.3e5, 2.9e6, 7.7e7, 3.3e9, 6.1e10]
 
 """
     recognize_sdf(f, dim=1; rtol=1e-12)
 
 README-style scripts pass closures such as `w -> (1 + w^2)^-2` (README.md:26).  Evaluated through the batched host
 callback they cost one host round trip per panel.  A closure that reproduces `phi (rho^2 + w^2)^-e`, `exp(-a|w|)` or
-`exp(-(w/a)^2)` to `rtol` at eleven probe frequencies over six decades (parameters solved from three of them, the
-others verify) is evaluated on the device instead.  Returns a catalogue SDF or `nothing`.
-`AdaptiveKernelConfig(f; sdf=:callback)` switches the matching off.
+`exp(-(w/a)^2)` to `rtol` at seventeen probe frequencies up to 6e10 (parameters solved from three of them, the
+others verify) is evaluated on the device instead -- announced with a warning, since the reference treats `f` as a
+black box.  Returns a catalogue SDF or `nothing`.  `AdaptiveKernelConfig(f; sdf=:callback)` switches the matching off.
 """
 function recognize_sdf(f, dim=1; rtol=1e-12)
   v = try Float64[f(w) for w in PROBES] catch; return nothing end
@@ -98,13 +100,39 @@ struct SkConfigArgs
   nufft_width::Cint
   hankel_min_lags::Cint
   sdf_dparam::Cint
+  batch_panels::Cint
 end
 
 # mirror of sk_stats
 struct SkStats
   n_unique::Int64; n_outer::Int64; n_panels::Int64; n_accepted::Int64; sum_active::Int64
   n_steps_launched::Int64; n_syncs::Int64; last_b::Float64
+  n_steps::Int64; n_rerun::Int64; sum_active_steps::Int64
 end
+
+# mirror of sk_kernel_times
+struct SkKernelTimes
+  total_ms::NTuple{5,Cdouble}; launches::NTuple{5,Int64}; active_items::NTuple{5,Int64}
+end
+
+# sizeof and field offsets of the three structs as the library this shim was written against compiled them
+# (sk_abi_layout; tests/test_host_logic.py compares these tuples with the built library).  check_abi() compares them
+# with the library that is actually loaded AND with Julia's own layout of the mirrors.
+const ABI_CONFIG_ARGS = (192, 0, 8, 72, 80, 88, 96, 104, 112, 120, 128, 132, 136, 140, 144, 152, 160, 168, 172, 176, 180, 184)
+const ABI_STATS = (88, 0, 8, 16, 24, 32, 40, 48, 56, 64, 72, 80)
+const ABI_KERNEL_TIMES = (120, 0, 40, 80)
+_jl_layout(T) = (sizeof(T), (Int(fieldoffset(T, i)) for i in 1:fieldcount(T))...)
+function check_abi()
+  for (which, T, want) in ((0, SkConfigArgs, ABI_CONFIG_ARGS), (1, SkStats, ABI_STATS), (2, SkKernelTimes, ABI_KERNEL_TIMES))
+    out = zeros(Csize_t, 64); len = Ref{Csize_t}(0)
+    _check(ccall((:sk_abi_layout, LIB), Cint, (Cint, Ptr{Csize_t}, Csize_t, Ref{Csize_t}), which, out, 64, len))
+    lib = Tuple(Int.(out[1:Int(len[])]))
+    lib == want || error("libspectralkernels_hip.so lays out struct $(which) as $(lib), this shim expects $(want)")
+    _jl_layout(T) == want || error("Julia lays out $(T) as $(_jl_layout(T)), the C ABI as $(want)")
+  end
+  true
+end
+__init__() = check_abi()
 
 # void (*sk_sdf_batch_fn)(const double* w, double* out, size_t n, void* ctx)
 function _sdf_batch(w::Ptr{Cdouble}, out::Ptr{Cdouble}, n::Csize_t, ctx::Ptr{Cvoid})::Cvoid
@@ -145,13 +173,16 @@ _kind(::Any)             = (Cint(0), ntuple(_ -> 0.0, 8), Cint(0))
 
 function AdaptiveKernelConfig(f; df=nothing, dim=1, alpha=0.0, tol::Float64=1e-8, derivative=false,
                               logw=false, convergence_criteria::Symbol=:both, tail=nothing,
-                              quadspec::Tuple{Int64,Int64}=(2^12, 2^4), device=-1, sdf::Symbol=:auto)
+                              quadspec::Tuple{Int64,Int64}=(2^12, 2^4), device=-1, sdf::Symbol=:auto, batch_panels=0)
   convergence_criteria in (:panel, :tails, :both) ||
     error("Argument convergence_criteria must be one of :panel, :tails, :both.")
   onsdf = f
   if !(f isa Union{MaternSDF,ExponentialSDF,GaussianSDF}) && sdf == :auto
     rec = recognize_sdf(f, dim)
-    isnothing(rec) || (onsdf = rec)
+    if !isnothing(rec)
+      @warn "AdaptiveKernelConfig: the SDF closure matches the device catalogue ($(rec)) at $(length(PROBES)) probe frequencies up to $(PROBES[end]) and is evaluated on the device; pass sdf=:callback to have the closure itself called in batches."
+      onsdf = rec
+    end
   end
   (kind, prm, dparam) = _kind(onsdf)
   fref = Ref{Any}(f)
@@ -164,7 +195,7 @@ function AdaptiveKernelConfig(f; df=nothing, dim=1, alpha=0.0, tol::Float64=1e-8
   crit = convergence_criteria == :both ? 0 : convergence_criteria == :panel ? 1 : 2
   args = SkConfigArgs(kind, prm, cb, ctx, dcb, dctx, dim, alpha, tol, derivative, logw, crit,
                       isnothing(tail) ? 0 : 1, isnothing(tail) ? 0.0 : Float64(tail),
-                      quadspec[1], quadspec[2], device, 0, 0, dparam)
+                      quadspec[1], quadspec[2], device, 0, 0, dparam, batch_panels)
   h = Ref{Ptr{Cvoid}}(C_NULL)
   code = _check(ccall((:sk_config_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{SkConfigArgs}), h, args))
   code == 100 && @warn(_last_error())                       # src/adaptive.jl:38
@@ -196,7 +227,7 @@ end
 
 # the panel schedule of the last call, printed like print_panel_info / print_panel_convergence (src/utils.jl:12-26)
 function _print_trace(cfg::AdaptiveKernelConfig, n::Integer)
-  st = Ref(SkStats(0, 0, 0, 0, 0, 0, 0, 0.0))
+  st = Ref(SkStats(0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0))
   ccall((:sk_last_stats, LIB), Cint, (Ptr{Cvoid}, Ref{SkStats}), cfg.handle, st)
   println("Reducing $(n) to $(st[].n_unique) unique lags for evaluation...")   # src/adaptive.jl:100
   rec = Matrix{Float64}(undef, 5, 4096); len = Ref{Csize_t}(0)
@@ -236,12 +267,41 @@ function kernel_values!(vals::Vector{Float64}, errs::Vector{Float64}, cfg::Adapt
   (vals, errs)
 end
 
+# Result vectors: the reference RETURNS two fresh Vectors (src/adaptive.jl:105-107).  Fresh pageable ones cost a page
+# fault per 4 KB plus a staging copy (1.5 ms for the 16 MB of 10^6 lags, against 0.3 ms of DMA), so large results come
+# from a pool of pinned vectors: handed out here, returned by their finalizer when the caller drops them, reused by later
+# calls -- already mapped, already pinned, written by DMA directly.
+const _POOL = Dict{Int,Vector{Ptr{Cvoid}}}()
+const _POOL_LOCK = ReentrantLock()
+function _pooled_vector(n::Integer)
+  nbytes = (8*max(n, 1) + 4095) & ~4095
+  p = lock(_POOL_LOCK) do
+    lst = get!(_POOL, nbytes, Ptr{Cvoid}[])
+    isempty(lst) ? C_NULL : pop!(lst)
+  end
+  if p == C_NULL
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    _check(ccall((:sk_host_alloc, LIB), Cint, (Ref{Ptr{Cvoid}}, Csize_t), r, nbytes))
+    p = r[]
+  end
+  v = unsafe_wrap(Vector{Float64}, Ptr{Float64}(p), n; own=false)
+  finalizer(v) do _
+    keep = lock(_POOL_LOCK) do
+      lst = get!(_POOL, nbytes, Ptr{Cvoid}[])
+      length(lst) < 8 ? (push!(lst, p); true) : false
+    end
+    keep || ccall((:sk_host_free, LIB), Cint, (Ptr{Cvoid},), p)
+  end
+  v
+end
+
 # src/adaptive.jl:95-108
 function kernel_values(cfg::AdaptiveKernelConfig, xs::AbstractVector{Float64};
                        k0=nothing, param_derivative=false, verbose=false)
   x = xs isa Vector{Float64} ? xs : Vector{Float64}(xs)
-  kernel_values!(Vector{Float64}(undef, length(x)), Vector{Float64}(undef, length(x)), cfg, x;
-                 k0=k0, param_derivative=param_derivative, verbose=verbose)
+  n = length(x)
+  (vals, errs) = n >= 4096 ? (_pooled_vector(n), _pooled_vector(n)) : (Vector{Float64}(undef, n), Vector{Float64}(undef, n))
+  kernel_values!(vals, errs, cfg, x; k0=k0, param_derivative=param_derivative, verbose=verbose)
 end
 
 function _multi(sym, cfgs, xs, k0arg, param_derivative)
@@ -307,6 +367,45 @@ function kernel_values_pairs(cfg::AdaptiveKernelConfig, pts::AbstractVector, pai
   (vals, errs)
 end
 
+"""
+    kernel_jacobian_pairs(cfgs, roles, cols, pts, pairs; k0, dlag=nothing, warp_cols=Int[], ncols)
+
+gen_kernel + gen_kernel_jacobian for point pairs on the device (src/model.jl:53-77, src/derivatives.jl:86-112): the lags
+`norm(pts[j] - pts[k])` of the (warped) points are formed on the device, ONE joint march evaluates every integrand and
+the Jacobian is assembled there.  `roles[t]` of `cfgs[t]`: 0 the kernel itself (`cfgs[1]`), 1 Jacobian column `cols[t]`
+(1-based) takes this integrand (`sdf_derivative(S, j)`, `logw=true`), 2 K' (`derivative=true`): column `warp_cols[q]`
+takes `K'(lag_e) * dlag[e, q]` with `dlag = d lag_e / d warp-parameter q` from the caller's differentiation of the warp
+(:46-54).  Returns `(vals, jac)`: the values of the reference's lookup table `Dict(raw_pairs .=> vals)` and the
+`length(pairs) x ncols` Jacobian.
+"""
+function kernel_jacobian_pairs(cfgs::AbstractVector{<:AdaptiveKernelConfig}, roles::AbstractVector{<:Integer},
+                               cols::AbstractVector{<:Integer}, pts::AbstractVector,
+                               pairs::AbstractVector{<:Tuple{Integer,Integer}}; k0, dlag=nothing,
+                               warp_cols::AbstractVector{<:Integer}=Int[], ncols::Integer)
+  pdim = length(first(pts))
+  p    = Matrix{Float64}(undef, pdim, length(pts))            # column-major pdim x npts == row-major npts x pdim
+  for (j, pt) in enumerate(pts), d in 1:pdim
+    p[d, j] = pt[d]
+  end
+  ix   = Matrix{Int64}(undef, 2, length(pairs))
+  for (e, (j, k)) in enumerate(pairs)
+    ix[1, e] = j - 1; ix[2, e] = k - 1
+  end
+  nwarp = length(warp_cols)
+  dl    = nwarp == 0 ? Float64[] : Matrix{Float64}(permutedims(dlag))   # row-major npairs x nwarp on the C side
+  hs    = Ptr{Cvoid}[c.handle for c in cfgs]
+  vals  = Vector{Float64}(undef, length(pairs))
+  jact  = Matrix{Float64}(undef, ncols, length(pairs))                  # row-major npairs x ncols
+  GC.@preserve cfgs begin
+    _check(ccall((:sk_kernel_jacobian_pairs, LIB), Cint,
+                 (Ptr{Ptr{Cvoid}}, Csize_t, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}, Csize_t, Cint, Ptr{Int64}, Csize_t, Cdouble,
+                  Ptr{Cdouble}, Cint, Ptr{Cint}, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
+                 hs, length(cfgs), Cint.(roles), Cint.(cols .- 1), p, length(pts), pdim, ix, length(pairs), Float64(k0),
+                 dl, nwarp, Cint.(warp_cols .- 1), ncols, vals, jact))
+  end
+  (vals, permutedims(jact))
+end
+
 # build_dense_cov_matrix(cfg, pts) -- src/utils.jl:41-64
 function build_dense_cov_matrix(cfg::AdaptiveKernelConfig, pts::AbstractVector)
   pdim = length(first(pts))
@@ -335,7 +434,7 @@ function ShardedKernelConfig(f; devices::AbstractVector{<:Integer}=Int[], kw...)
   crit = base.convergence_criteria == :both ? 0 : base.convergence_criteria == :panel ? 1 : 2
   args = SkConfigArgs(kind, prm, C_NULL, C_NULL, C_NULL, C_NULL, base.dim, base.alpha, base.tol, base.derivative,
                       base.logw, crit, isnothing(base.tail) ? 0 : 1, isnothing(base.tail) ? 0.0 : base.tail,
-                      base.quadspec[1], base.quadspec[2], -1, 0, 0, dparam)
+                      base.quadspec[1], base.quadspec[2], -1, 0, 0, dparam, 0)
   nd = Ref{Cint}(0); ccall((:sk_device_count, LIB), Cint, (Ref{Cint},), nd)
   devs = isempty(devices) ? Cint.(0:nd[]-1) : Cint.(devices)
   h = Ref{Ptr{Cvoid}}(C_NULL)

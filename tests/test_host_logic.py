@@ -171,3 +171,18 @@ def test_staged_upload_order_scan_alternating_arrays():
         bad = base.copy()
         bad[e] = bad[e - 1] - 1e-9
         assert scan(bad, 8) == 2, e
+
+
+def test_abi_struct_layouts_match_the_mirrors():
+    """the structs that cross the C ABI are mirrored by hand (ctypes here, the Julia shim): sizes and field
+    offsets as compiled (sk_abi_layout) against the ctypes mirrors and against the constants written next to the Julia
+    structs in spectralkernels.jl_amd/julia/SpectralKernelsHIP.jl."""
+    import re
+    from spectralkernels_jl_amd import _lib
+    for which, cls in ((0, _lib.ConfigArgs), (1, _lib.Stats), (2, _lib.KernelTimes)):
+        assert _lib.abi_layout(which) == _lib.mirror_layout(cls), (which, _lib.abi_layout(which), _lib.mirror_layout(cls))
+    jl = open(os.path.join(ROOT, "spectralkernels.jl_amd", "julia", "SpectralKernelsHIP.jl")).read()
+    for which, name in ((0, "ABI_CONFIG_ARGS"), (1, "ABI_STATS"), (2, "ABI_KERNEL_TIMES")):
+        m = re.search(r"const %s = \(([^)]*)\)" % name, jl)
+        assert m, name
+        assert [int(x) for x in m.group(1).replace(" ", "").split(",") if x] == _lib.abi_layout(which), name
