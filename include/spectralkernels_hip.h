@@ -195,7 +195,20 @@ void sk_sharded_destroy(sk_sharded* sh);
 int sk_sharded_count(const sk_sharded* sh);
 int sk_kernel_values_sharded(sk_sharded* sh, const double* xs, size_t n, double k0, int has_k0, int param_derivative,
                              double* vals_out, double* errs_out);
-/* Last call, per shard: panel statistics, wall time (ms) and block [lo, hi) of the sorted unique set. */
+/* Split of the sorted unique lag set over the shards: 0 = contiguous blocks (default), 1 = strided (shard s takes lags
+ * s, s + ns, ...: every shard sees the whole lag range, hence the same panel schedule and equal work -- the blocks'
+ * schedules differ, the block with the smallest lags marches longest). */
+int sk_sharded_set_split(sk_sharded* sh, int strided);
+/* kernel_values on the lags of point pairs (sk_kernel_values_pairs: src/model.jl:64-65, src/utils.jl:41-64), sharded:
+ * the points are replicated, the pair list (or the dense list "0 followed by all i < j" for pairs == NULL) is cut into
+ * contiguous blocks, one per device; every device forms the lags of its block, sorts and deduplicates them and marches
+ * on them -- no lag array and no sort on the host.  vals/errs in pair order.  BASELINE config 4: 10^6 pairwise lags
+ * across the GPUs of a node in one call. */
+int sk_kernel_values_pairs_sharded(sk_sharded* sh, const double* pts, size_t npts, int pdim, const int64_t* pairs,
+                                   size_t npairs, double k0, int has_k0, int param_derivative, double* vals_out,
+                                   double* errs_out);
+/* Last call, per shard: panel statistics, wall time (ms) and block [lo, hi) of the sorted unique set (strided: first
+ * index and the set's size; pairs: block of the pair list). */
 int sk_sharded_last(const sk_sharded* sh, int shard, sk_stats* st, double* ms, int64_t* lo, int64_t* hi);
 /* Test hook (CPU tier): shards whose device call is replaced by `fn` (same meaning as sk_kernel_values with
  * has_k0 = 1 on the block) -- exercises the split / dedup / merge logic without a device. */

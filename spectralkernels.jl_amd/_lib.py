@@ -86,6 +86,8 @@ def load():
     L.sk_sharded_destroy.restype = None
     L.sk_sharded_count.argtypes = [vp]
     L.sk_kernel_values_sharded.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp]
+    L.sk_sharded_set_split.argtypes = [vp, C.c_int]
+    L.sk_kernel_values_pairs_sharded.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp]
     L.sk_sharded_last.argtypes = [vp, C.c_int, C.POINTER(Stats), dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sk_last_stats.argtypes = [vp, C.POINTER(Stats)]
     L.sk_last_trace.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]

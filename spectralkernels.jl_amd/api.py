@@ -569,7 +569,7 @@ class ShardedKernelConfig:
     contiguous blocks (sk_sharded_create / sk_kernel_values_sharded).  `backend`: CPU-tier test hook replacing the
     device call of a shard, callable(shard, xs, k0, param_derivative) -> (vals, errs)."""
 
-    def __init__(self, f=None, devices=None, n_devices=None, backend=None, n_shards=None, **kw):
+    def __init__(self, f=None, devices=None, n_devices=None, backend=None, n_shards=None, split="blocked", **kw):
         self._h = None
         lib = L.load()
         h = C.c_void_p()
@@ -600,6 +600,9 @@ class ShardedKernelConfig:
                 warnings.warn(L.last_error())
         self._h = h
         self.n_shards = lib.sk_sharded_count(h)
+        if split not in ("blocked", "strided"):
+            raise SpectralKernelsError(L.SK_EINVAL, "split must be 'blocked' or 'strided'")
+        _check(lib.sk_sharded_set_split(h, 1 if split == "strided" else 0))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -617,6 +620,26 @@ class ShardedKernelConfig:
                                                  0.0 if k0 is None else float(k0), 0 if k0 is None else 1,
                                                  int(bool(param_derivative)), vals.ctypes.data_as(C.c_void_p),
                                                  errs.ctypes.data_as(C.c_void_p)))
+        return vals, errs
+
+    def kernel_values_pairs(self, pts, pairs=None, k0=None, param_derivative=False):
+        """kernel_values on the lags |pts[j] - pts[k]| of index pairs (None: the dense list "0 then all i < j",
+        src/utils.jl:43-46), the pair list cut into one block per device; lags are formed, sorted and deduplicated on
+        the devices (sk_kernel_values_pairs_sharded)."""
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        if pts.ndim == 1:
+            pts = pts[:, None]
+        npts, pdim = pts.shape
+        if pairs is None:
+            n, pp, npairs = 1 + npts * (npts - 1) // 2, None, 0
+        else:
+            pr = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+            n, pp, npairs = pr.shape[0], pr.ctypes.data_as(C.c_void_p), pr.shape[0]
+        vals, errs = np.zeros(n), np.zeros(n)
+        _check(L.load().sk_kernel_values_pairs_sharded(self._h, pts.ctypes.data_as(C.c_void_p), npts, pdim, pp, npairs,
+                                                       0.0 if k0 is None else float(k0), 0 if k0 is None else 1,
+                                                       int(bool(param_derivative)), vals.ctypes.data_as(C.c_void_p),
+                                                       errs.ctypes.data_as(C.c_void_p)))
         return vals, errs
 
     def last(self):

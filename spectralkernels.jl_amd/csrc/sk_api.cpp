@@ -677,6 +677,45 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   return SK_OK;
 }
 
+// grow-only device buffers
+static int ensure_dev(void** buf, size_t* have, size_t bytes) {
+  if (bytes <= *have) return SK_OK;
+  if (*buf) HIPCHK(hipFree(*buf));
+  *buf = nullptr;
+  *have = 0;
+  HIPCHK(hipMalloc(buf, bytes + bytes / 4));
+  *have = bytes + bytes / 4;
+  return SK_OK;
+}
+
+// Sort + dedup of host lags on the config's device (the sharded entry's unsorted input): staged upload, rocPRIM
+// radix sort + scan as in kernel_values_device_impl, unique set and inverse map back to the host.
+int sort_unique_on_device(sk_config* cfg, const double* xs, size_t n, std::vector<double>& uxs, std::vector<int64_t>& inv) {
+  HIPCHK(hipSetDevice(cfg->device));
+  hipStream_t st = cfg->own_stream;
+  const size_t a8 = ((n * 8 + 255) / 256) * 256;
+  const size_t tb = sort_unique_temp_bytes((long long)n);
+  int rc = ensure_dev(&cfg->d_aux, &cfg->aux_bytes, 3 * a8 + tb + 512);
+  if (rc) return rc;
+  char* buf = (char*)cfg->d_aux;
+  double* d_xs = (double*)buf;
+  double* d_ux = (double*)(buf + a8);
+  long long* d_inv = (long long*)(buf + 2 * a8);
+  long long* d_nu = (long long*)(buf + 3 * a8);
+  void* tmp = buf + 3 * a8 + 256;
+  rc = h2d_doubles(cfg, d_xs, xs, n, st, nullptr);
+  if (rc) return rc;
+  sort_unique(d_xs, (long long)n, d_ux, d_inv, d_nu, tmp, tb, st);
+  HIPCHK(hipMemcpyAsync(cfg->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const size_t nu = (size_t)*cfg->h_nuniq;
+  uxs.resize(nu);
+  inv.resize(n);
+  rc = d2h_doubles(cfg, uxs.data(), d_ux, nu, st);
+  if (!rc) rc = d2h_doubles(cfg, (double*)inv.data(), (const double*)d_inv, n, st);  // 8-byte words
+  return rc;
+}
+
 }  // namespace sk
 
 // ====================================================================== C ABI
@@ -1078,17 +1117,6 @@ int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double
   return kernel_values_device_order(cfg, d_xs, n, k0, param_derivative, d_vals, d_errs, st, SK_ORDER_UNKNOWN);
 }
 
-// grow-only device buffers
-static int ensure_dev(void** buf, size_t* have, size_t bytes) {
-  if (bytes <= *have) return SK_OK;
-  if (*buf) HIPCHK(hipFree(*buf));
-  *buf = nullptr;
-  *have = 0;
-  HIPCHK(hipMalloc(buf, bytes + bytes / 4));
-  *have = bytes + bytes / 4;
-  return SK_OK;
-}
-
 static double ms_since(const std::chrono::steady_clock::time_point& t0) {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -1272,6 +1300,49 @@ int sk_kernel_values_pairs(sk_config* cfg, const double* pts, size_t npts, int p
   if (!rc) rc = d2h_doubles2(cfg, vals_out, errs_out, d + n, n, st);
   return rc;
 }
+
+}  // extern "C"
+
+namespace sk {
+// Entries [e0, e0 + count) of a pair list (pairs != NULL) or of the dense list "0 followed by all i < j" (pairs == NULL):
+// a shard's block of sk_kernel_values_pairs_sharded.  Points and the block's pairs go up, the lags are formed, sorted
+// and deduplicated on this config's device, the results of the block come down in pair order.
+int kernel_values_pairs_range(sk_config* cfg, const double* pts, size_t npts, int pdim, const int64_t* pairs, size_t e0,
+                              size_t count, double k0, int param_derivative, double* vals_out, double* errs_out) {
+  if (!cfg) return fail(SK_EINVAL, "null config");
+  if (count == 0) return SK_OK;
+  HIPCHK(hipSetDevice(cfg->device));
+  int rc = ensure_lags(cfg, count);
+  if (rc) return rc;
+  hipStream_t st = cfg->own_stream;
+  const size_t pts_d = npts * (size_t)pdim, pts_b = ((pts_d * 8 + 255) / 256) * 256;
+  rc = ensure_dev(&cfg->d_aux, &cfg->aux_bytes, pts_b + (pairs ? 2 * count * sizeof(int64_t) : 0));
+  if (rc) return rc;
+  double* d_pts = (double*)cfg->d_aux;
+  int64_t* d_pairs = pairs ? (int64_t*)((char*)cfg->d_aux + pts_b) : nullptr;
+  rc = h2d_doubles(cfg, d_pts, pts, pts_d, st, nullptr);
+  if (!rc && pairs) {
+    if (hipStreamSynchronize(st) != hipSuccess) rc = fail(SK_EHIP, "stream synchronisation failed");
+    if (!rc) rc = h2d_doubles(cfg, (double*)d_pairs, (const double*)(pairs + 2 * e0), 2 * count, st, nullptr);
+  }
+  if (rc) return rc;
+  size_t need = count * sizeof(double);
+  if (need > cfg->pl_bytes) {
+    if (cfg->d_plags) HIPCHK(hipFree(cfg->d_plags));
+    cfg->d_plags = nullptr;
+    cfg->pl_bytes = 0;
+    HIPCHK(hipMalloc((void**)&cfg->d_plags, need + need / 4));
+    cfg->pl_bytes = need + need / 4;
+  }
+  launch_pair_lags(d_pts, (long long)npts, pdim, (const long long*)d_pairs, (long long)count, cfg->d_plags, st, (long long)e0);
+  double* d = cfg->d_lags;
+  rc = sk_kernel_values_device(cfg, cfg->d_plags, count, k0, param_derivative, d + count, d + 2 * count, st);
+  if (!rc) rc = d2h_doubles2(cfg, vals_out, errs_out, d + count, count, st);
+  return rc;
+}
+}  // namespace sk
+
+extern "C" {
 
 int sk_dense_cov_matrix_device(sk_config* cfg, const double* d_pts, size_t npts, int pdim, double* d_out, void* stream) {
   if (!cfg) return fail(SK_EINVAL, "null config");

@@ -312,7 +312,7 @@ void launch_direct(const double* nodes, const double* coef, int64_t M, const dou
 
 // callers' side: pairwise lags and the dense covariance matrix (src/model.jl:64-65, src/utils.jl:41-64)
 void launch_pair_lags(const double* pts, long long npts, int pdim, const long long* pairs, long long npairs, double* lags,
-                      hipStream_t st);
+                      hipStream_t st, long long e0 = 0);
 void launch_fill_cov(const double* vals, long long npts, double* out, hipStream_t st);
 
 // sort / dedup helpers

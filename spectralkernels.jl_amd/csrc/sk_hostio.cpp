@@ -148,7 +148,8 @@ int h2d_doubles(sk_config* cfg, double* d_dst, const double* src, size_t cnt, hi
   if (cfg->chunk_done.size() < nch) cfg->chunk_done = std::vector<std::atomic<int>>(nch + 8);
   for (size_t c = 0; c < nch; ++c) cfg->chunk_done[c].store(0, std::memory_order_relaxed);
   std::atomic<int> err{0};
-  const int f = stage_chunks(stage, src, edge, cfg->chunk_done, order != nullptr, copy_threads(), [&](size_t lo, size_t hi) {
+  const int nthr = cfg->copy_threads > 0 ? cfg->copy_threads : copy_threads();
+  const int f = stage_chunks(stage, src, edge, cfg->chunk_done, order != nullptr, nthr, [&](size_t lo, size_t hi) {
     if (hipMemcpyAsync(d_dst + lo, stage + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
       err.store(1);
   });
@@ -201,7 +202,7 @@ int d2h_doubles2(sk_config* cfg, double* dst_a, double* dst_b, const double* d_s
     HIPCHK(hipEventRecord(cfg->cp_events[c], st));
   }
   std::atomic<long long> ready{0};  // chunks landed in the staging buffer; -1: a copy failed
-#pragma omp parallel num_threads(copy_threads())
+#pragma omp parallel num_threads(cfg->copy_threads > 0 ? cfg->copy_threads : copy_threads())
   {
     const int nt = omp_get_num_threads(), q = omp_get_thread_num();
     for (size_t c = 0; c < nch; ++c) {

@@ -2217,9 +2217,11 @@ __device__ __forceinline__ void dense_pair(long long e, long long npts, long lon
   j = ii + 1 + (e - (ii * npts - ii * (ii + 1) / 2));
 }
 __global__ void k_pair_lags(const double* pts, long long npts, int pdim, const long long* pairs, long long npairs,
-                            double* lags) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= npairs) return;
+                            double* lags, long long e0) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= npairs) return;
+  const long long e = pairs ? q : e0 + q;  // dense list: entries [e0, e0 + npairs) (a shard's block)
+  lags += pairs ? 0 : -e0;
   long long i, j;
   if (pairs) {
     i = pairs[2 * e];
@@ -2248,8 +2250,8 @@ __global__ void k_pair_lags(const double* pts, long long npts, int pdim, const l
   lags[e] = s;
 }
 void launch_pair_lags(const double* pts, long long npts, int pdim, const long long* pairs, long long npairs, double* lags,
-                      hipStream_t st) {
-  hipLaunchKernelGGL(k_pair_lags, dim3(nblk(npairs, 256)), dim3(256), 0, st, pts, npts, pdim, pairs, npairs, lags);
+                      hipStream_t st, long long e0) {
+  hipLaunchKernelGGL(k_pair_lags, dim3(nblk(npairs, 256)), dim3(256), 0, st, pts, npts, pdim, pairs, npairs, lags, e0);
 }
 // src/utils.jl:54-61: symmetric fill from the dense pair list
 __global__ void k_fill_cov(const double* vals, long long npts, double* out) {

@@ -85,3 +85,75 @@ def test_errors(sk, oracle):
     assert "shard 1" in str(ex.value)
     v, e = sk.ShardedKernelConfig(backend=be, n_shards=2).kernel_values(np.array([]), k0=1.0)
     assert v.size == 0
+
+
+@pytest.mark.parametrize("nshard", [2, 8])
+def test_strided_split_same_range_on_every_shard(sk, oracle, nshard):
+    """sk_sharded_set_split(strided): shard s takes lags s, s + ns, ... of the sorted unique set -- every shard sees the
+    whole lag range (same panel schedule, equal work), results scattered back in place (VERDICT r2 #4)."""
+    calls = []
+    ocfg, be = _backend(oracle, calls)
+    sh = sk.ShardedKernelConfig(backend=be, n_shards=nshard, split="strided")
+    rng = np.random.default_rng(4)
+    xs = np.r_[np.sort(rng.uniform(0.0, 1.0, 57)), 0.3, 0.3, 0.0]
+    rng.shuffle(xs)
+    v, e = sh.kernel_values(xs, k0=np.pi / 2)
+    uniq = np.unique(xs)
+    for shard, seen in calls:
+        assert np.array_equal(seen, uniq[shard::nshard])
+    assert sorted(c[0] for c in calls) == list(range(nshard))
+    sizes = [c[1].size for c in calls]
+    assert max(sizes) - min(sizes) <= 1 and sum(sizes) == uniq.size
+    # each shard's largest lag is within one stride of the global one: same first panel width up to that
+    tops = [c[1][-1] for c in calls]
+    assert min(tops) >= uniq[-nshard]
+    v1, e1 = oracle.kernel_values(ocfg, xs, k0=np.pi / 2)
+    assert np.abs(v - v1).max() <= 1e-8 * np.pi / 2
+    assert np.array_equal(np.isnan(e), np.isnan(e1))
+
+
+def test_large_unsorted_input_goes_through_the_parallel_host_sort(sk, oracle):
+    # 2e5 lags with duplicates: the injected tier has no device, so the dedup is the parallel merge sort of sk_shard.cpp
+    rng = np.random.default_rng(9)
+    base = rng.uniform(0.0, 2.0, 150000)
+    xs = np.r_[base, base[:50000], 0.0, -0.0]
+    rng.shuffle(xs)
+    seen = []
+    be = lambda shard, x, k0, pd: (seen.append(x.copy()) or (2.0 * x + 1.0, x * 0.5))
+    sh = sk.ShardedKernelConfig(backend=be, n_shards=4)
+    v, e = sh.kernel_values(xs, k0=1.0)
+    assert np.array_equal(v, 2.0 * np.abs(xs) + 1.0) and np.array_equal(e, np.abs(xs) * 0.5)
+    allseen = np.concatenate(seen)
+    assert np.array_equal(np.sort(allseen), np.unique(xs)) and all(np.all(np.diff(s) > 0) for s in seen)
+
+
+@pytest.mark.parametrize("nshard", [2, 8])
+def test_pairs_sharded_blocks_of_the_pair_list(sk, oracle, nshard):
+    """sk_kernel_values_pairs_sharded (BASELINE config 4's call shape): points replicated, the pair list cut into one
+    block per shard, each shard's lags formed / sorted / deduplicated by the shard itself; results in pair order."""
+    rng = np.random.default_rng(12)
+    pts = rng.uniform(0.0, 1.0, (40, 2))
+    pairs = np.array([(i, j) for i in range(40) for j in range(i, 40) if (i + j) % 3 != 1], dtype=np.int64)
+    seen = []
+
+    def be(shard, x, k0, pd):
+        assert np.all(np.diff(x) > 0)  # sorted unique, as a device shard's march gets them
+        seen.append((shard, x.size))
+        return np.exp(-x), x * x
+
+    sh = sk.ShardedKernelConfig(backend=be, n_shards=nshard)
+    v, e = sh.kernel_values_pairs(pts, pairs, k0=1.0)
+    lag = np.sqrt(((pts[pairs[:, 0]] - pts[pairs[:, 1]]) ** 2).sum(1))
+    assert np.allclose(v, np.exp(-lag), rtol=0, atol=1e-15) and np.allclose(e, lag * lag, rtol=0, atol=1e-15)
+    info = sh.last()
+    assert info[0]["lo"] == 0 and info[-1]["hi"] == len(pairs) and all(a["hi"] == b["lo"] for a, b in zip(info, info[1:]))
+    assert sorted(s for s, _ in seen) == list(range(nshard))
+    # the dense list of build_dense_cov_matrix (src/utils.jl:43-46): 0, then |p_i - p_j| for i < j
+    seen.clear()
+    vd, ed = sh.kernel_values_pairs(pts[:17], None, k0=1.0)
+    dl = np.r_[0.0, [np.linalg.norm(pts[i] - pts[j]) for i in range(17) for j in range(i + 1, 17)]]
+    assert vd.size == 1 + 17 * 16 // 2
+    assert np.allclose(vd, np.exp(-dl), rtol=0, atol=1e-15) and np.allclose(ed, dl * dl, rtol=0, atol=1e-15)
+    # 1-D points
+    v1, _ = sh.kernel_values_pairs(pts[:9, 0], np.array([(0, 5), (8, 2), (3, 3)]), k0=1.0)
+    assert np.allclose(v1, np.exp(-np.abs([pts[0, 0] - pts[5, 0], pts[8, 0] - pts[2, 0], 0.0])), rtol=0, atol=1e-15)
