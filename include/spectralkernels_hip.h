@@ -163,9 +163,13 @@ int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs
  * one transform per integrand, two for logw) and the running sums.  A (sub)panel is accepted when every integrand
  * passes max|I2-I1| < tol |k0| (src/quadrature.jl:260), a lag retires when every integrand's convergence predicate
  * holds (src/adaptive.jl:183-198): results within tol of the separate marches of sk_kernel_values_multi, whose
- * schedules can only be shorter.  cfgs[0] must be the plain kernel (derivative = logw = 0); all configs: dim 1,
- * catalogue SDFs (incl. sdf_dparam), equal quadspec / tol / alpha / criteria / tail; one k0 for all, as the
- * reference passes it (src/derivatives.jl:57,71,81).  vals_out / errs_out: ncfg x n. */
+ * schedules can only be shorter.  cfgs[0] must be the plain kernel (derivative = logw = 0); all configs: one dim,
+ * equal quadspec / tol / alpha / criteria / tail, at most one logw integrand; one k0 for all, as the reference passes
+ * it (src/derivatives.jl:57,71,81).  dim 1: type-3 NUFFT with one transform per integrand; even dim >= 2: the direct
+ * Bessel sums of src/quadrature.jl:145-160 with J_nu(2 pi w r) evaluated once per (lag, node) for all integrands (lag
+ * sets of hankel_min_lags and more take one fast-Hankel march per integrand instead).  SDFs: all catalogue entries
+ * (incl. sdf_dparam), evaluated on the device, or all host callbacks, each called once per panel on all its nodes
+ * (no logw integrand then).  vals_out / errs_out: ncfg x n. */
 int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, double k0,
                            const int* param_derivative, double* vals_out, double* errs_out);
 

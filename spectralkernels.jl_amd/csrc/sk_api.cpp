@@ -303,6 +303,7 @@ static int wait_status(sk_config* cfg, unsigned int seq, hipStream_t st) {
 }
 
 int joint_wait_status(sk_config* cfg, unsigned int seq, hipStream_t st) { return wait_status(cfg, seq, st); }
+void joint_host_nodes(const sk_config* cfg, const PanelParams& pp, std::vector<double>& w) { host_nodes(cfg, pp, w); }
 
 // core march on sorted unique lags already on the device (src/adaptive.jl:110-202)
 static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0, double ks0, double* d_ks, double* d_errs,
@@ -1052,6 +1053,8 @@ void sk_config_destroy(sk_config* cfg) {
   if (cfg->h_out) hipHostFree(cfg->h_out);
   if (cfg->d_aux) hipFree(cfg->d_aux);
   if (cfg->d_joint) hipFree(cfg->d_joint);
+  if (cfg->d_jfv) hipFree(cfg->d_jfv);
+  if (cfg->h_jfv) hipHostFree(cfg->h_jfv);
   for (int q = 0; q <= kJointTr; ++q) {
     if (cfg->plan_joint[q]) rocfft_plan_destroy(cfg->plan_joint[q]);
     if (cfg->info_joint[q]) rocfft_execution_info_destroy(cfg->info_joint[q]);

@@ -71,6 +71,9 @@ struct sk_config {
   // joint march (sk_joint.cpp): grow-only buffers, one rocFFT plan per number of raw transforms
   void* d_joint = nullptr;
   size_t joint_bytes = 0;
+  double* d_jfv = nullptr;         // joint march on callback SDFs: integrand values of a panel, ntr x 3M (device / pinned)
+  double* h_jfv = nullptr;
+  size_t jfv_count = 0;
   rocfft_plan plan_joint[kJointTr + 1] = {};
   rocfft_execution_info info_joint[kJointTr + 1] = {};
   void* fft_work_joint[kJointTr + 1] = {};

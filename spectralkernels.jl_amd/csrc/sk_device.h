@@ -294,9 +294,16 @@ void launch_fix_b(const DevConst& dc, const DevBuffers& db, long long lo, long l
 
 // joint march (sk_joint_kernels.inc)
 void launch_joint_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const JointSpec& js, const JointBufs& jb,
-                         int slot, hipStream_t st);
+                         int slot, const double* fv /* host-callback integrand values, ntr x 3M, or nullptr */, hipStream_t st);
 void launch_joint_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const JointSpec& js, const JointBufs& jb,
                          int slot, long long n, hipStream_t st);
+
+// dim >= 2: strengths of every raw transform (fv != nullptr: integrand values from the host callbacks, ntr x 3M),
+// then the direct Bessel sums of all transforms in one pass over the sources
+void launch_joint_strengths(const DevConst& dc, const DevBuffers& db, const JointSpec& js, const JointBufs& jb, int slot,
+                            const double* fv, hipStream_t st);
+void launch_bessel_joint(const DevConst& dc, const DevBuffers& db, const JointSpec& js, const JointBufs& jb, int slot, long long n,
+                         hipStream_t st);
 
 void launch_jac_assemble(const double* vals, long long n, int ncfg, const int* map, const double* dlag, int nwarp, int t_warp,
                          int ncols, double* jac, hipStream_t st);

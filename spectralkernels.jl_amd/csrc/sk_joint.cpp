@@ -15,6 +15,7 @@
 
 namespace sk {
 int joint_wait_status(sk_config* cfg, unsigned int seq, hipStream_t st);  // sk_api.cpp (wait_status)
+void joint_host_nodes(const sk_config* cfg, const PanelParams& pp, std::vector<double>& w);  // sk_api.cpp (host_nodes)
 }
 
 namespace {
@@ -55,8 +56,12 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
     if (!c) return fail(SK_EINVAL, "null config");
     const sk_config_args& a = c->args;
     if (c->device != c0->device) return fail(SK_EINVAL, "joint march: configs must live on one device");
-    if (a.dim != 1) return fail(SK_EUNSUPPORTED, "joint march: dim must be 1");
-    if (a.sdf_kind == SK_SDF_CALLBACK) return fail(SK_EUNSUPPORTED, "joint march: catalogue SDFs only (the integrands are evaluated on the device)");
+    if (a.dim != c0->args.dim) return fail(SK_EINVAL, "joint march: the configs must have one dim");
+    // catalogue SDFs are evaluated on the device; host callbacks once per panel for all integrands -- not mixed
+    if ((a.sdf_kind == SK_SDF_CALLBACK) != (c0->args.sdf_kind == SK_SDF_CALLBACK))
+      return fail(SK_EUNSUPPORTED, "joint march: all integrands catalogue SDFs or all host callbacks");
+    if (a.sdf_kind == SK_SDF_CALLBACK && a.logw)
+      return fail(SK_EUNSUPPORTED, "joint march: logw with a callback SDF (use sk_kernel_values_multi)");
     if (c->m != c0->m || c->k != c0->k || a.tol != c0->args.tol || a.alpha != c0->args.alpha || a.criteria != c0->args.criteria ||
         a.has_tail != c0->args.has_tail || (a.has_tail && a.tail != c0->args.tail) || c->dc.w != c0->dc.w)
       return fail(SK_EINVAL, "joint march: quadspec, tol, alpha, convergence_criteria, tail and NUFFT width must agree");
@@ -175,21 +180,64 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
   std::memset(&c0->stats, 0, sizeof(c0->stats));
   c0->stats.n_unique = nu;
   const DevState* hs = &c0->h_status->state;
-  int t = 0, mode = SK_MODE_INIT, R = 2;
+  // dim >= 2: direct Bessel sums with shared J_nu evaluations (sk_joint_kernels.inc, "dim >= 2"); callback SDFs: the
+  // host evaluates every integrand at the panel's nodes, so it needs the state before each step (one step per round)
+  const bool bessel = c0->args.dim > 1;
+  const bool cb = c0->args.sdf_kind == SK_SDF_CALLBACK;
+  const size_t M3 = (size_t)3 * c0->M;
+  const double* d_fv = nullptr;
+  if (cb) {
+    if (c0->jfv_count < (size_t)ntr * M3) {
+      if (c0->d_jfv) HIPCHK(hipFree(c0->d_jfv));
+      if (c0->h_jfv) HIPCHK(hipHostFree(c0->h_jfv));
+      c0->d_jfv = nullptr;
+      c0->h_jfv = nullptr;
+      c0->jfv_count = 0;
+      HIPCHK(hipMalloc((void**)&c0->d_jfv, sizeof(double) * (size_t)kJointTr * M3));
+      HIPCHK(hipHostMalloc((void**)&c0->h_jfv, sizeof(double) * (size_t)kJointTr * M3, hipHostMallocDefault));
+      c0->jfv_count = (size_t)kJointTr * M3;
+    }
+    d_fv = c0->d_jfv;
+  }
+  int t = 0, mode = SK_MODE_INIT, R = cb ? 1 : 2;
   for (;;) {
+    if (cb) {
+      const unsigned int seq = ++c0->seq;
+      launch_advance(dcj, db, mode, t, nu, k0, jb.ks0[0], seq, st);
+      rc = joint_wait_status(c0, seq, st);
+      if (rc) return rc;
+      if (hs->done) break;
+      // every integrand at the nodes of this (sub)panel, and |f_t(b)| for the tail fits (src/adaptive.jl:204-220)
+      joint_host_nodes(c0, hs->pp, c0->h_nodes);
+      for (int r = 0; r < ntr; ++r) cfgs[js.tr[r].out]->sdf.batch(c0->h_nodes.data(), c0->h_jfv + (size_t)r * M3, M3);
+      HIPCHK(hipMemcpyAsync(c0->d_jfv, c0->h_jfv, sizeof(double) * (size_t)ntr * M3, hipMemcpyHostToDevice, st));
+      if (hs->tail_pending) {
+        for (int tt = 0; tt < nt; ++tt) {
+          c0->h_scal[16 + tt] = std::fabs(cfgs[tt]->sdf(hs->b));
+          HIPCHK(hipMemcpyAsync(&db.state[t & 1].jtail[tt].t1, &c0->h_scal[16 + tt], sizeof(double), hipMemcpyHostToDevice, st));
+        }
+      }
+      mode = SK_MODE_ASIS;
+    }
     for (int r = 0; r < R; ++r) {
       launch_gen(dcj, db, mode, t, nu, k0, jb.ks0[0], SK_G_WEIGHT, st);
-      launch_joint_spread(dcj, c0->d_ec, db, js, jb, t & 1, st);
-      {
-        void* in[1] = {jb.fft};
-        void* out[1] = {jb.fft_out};
-        FFTCHK(rocfft_execute(c0->plan_joint[ntr], in, out, c0->info_joint[ntr]));
+      if (bessel) {
+        launch_joint_strengths(dcj, db, js, jb, t & 1, d_fv, st);
+        launch_bessel_joint(dcj, db, js, jb, t & 1, nu, st);
+      } else {
+        launch_joint_spread(dcj, c0->d_ec, db, js, jb, t & 1, d_fv, st);
+        {
+          void* in[1] = {jb.fft};
+          void* out[1] = {jb.fft_out};
+          FFTCHK(rocfft_execute(c0->plan_joint[ntr], in, out, c0->info_joint[ntr]));
+        }
+        launch_joint_interp(dcj, c0->d_ec, db, js, jb, t & 1, nu, st);
       }
-      launch_joint_interp(dcj, c0->d_ec, db, js, jb, t & 1, nu, st);
       ++t;
       mode = SK_MODE_TRANSITION;
       c0->stats.n_steps_launched++;
     }
+    if (cb) continue;
     const unsigned int seq = ++c0->seq;
     launch_advance(dcj, db, mode, t, nu, k0, jb.ks0[0], seq, st);
     rc = joint_wait_status(c0, seq, st);
@@ -252,6 +300,15 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
 extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, double k0,
                                       const int* param_derivative, double* vals_out, double* errs_out) {
   if (!xs && n) return fail(SK_EINVAL, "null lags");
+  if (cfgs && ncfg && cfgs[0] && cfgs[0]->args.dim > 1) {
+    // dim >= 2: the joint march evaluates direct Bessel sums (O(lags x nodes) per panel, the reference's own branch
+    // for its 136-lag Jacobian tests); big lag sets go through the fast Hankel transform, one march per integrand
+    const int hk_min = cfgs[0]->args.hankel_min_lags == 0 ? 2048 : cfgs[0]->args.hankel_min_lags;
+    if (hk_min > 0 && n >= (size_t)hk_min) {
+      std::vector<double> k0s(ncfg, k0);
+      return sk_kernel_values_multi(cfgs, ncfg, xs, n, k0s.data(), param_derivative, vals_out, errs_out);
+    }
+  }
   static const bool timing = getenv("SK_JOINT_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   double *dv = nullptr, *de = nullptr;
