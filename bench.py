@@ -288,9 +288,14 @@ def main():
     # dominant kernel: the interpolation launch (largest share of device time in the rocprofv3 kernel stats,
     # profiles/*_summary.txt; the HIP-event brackets add the launch gap to whichever kernel follows a host
     # synchronisation, so the event totals of interpolation and spread are too close to rank them reliably)
-    dom = "interp" if acc.get("interp", {}).get("launches", 0) > 0 else max(acc, key=lambda k: acc[k]["total_ms"])
     batched = w["kw"].get("dim", 1) == 1
-    dom_name = "k_interp_b" if (dom == "interp" and batched) else ("k_hk_interp" if dom == "interp" else "k_" + dom)
+    if batched:
+        dom = "interp" if acc.get("interp", {}).get("launches", 0) > 0 else max(acc, key=lambda k: acc[k]["total_ms"])
+    else:  # dim >= 2 (fast Hankel transform): whatever the events say takes longest -- spread, FFT, interpolation or near field
+        dom = max((k for k in acc if k != "advance"), key=lambda k: acc[k]["total_ms"])
+    hk_names = {"gen": "k_gen", "spread": "k_spread_multi", "fft": "rocfft (batch 2 x series terms, length n2)",
+                "interp": "k_hk_interp", "near": "k_hk_near + k_hk_cheb"}
+    dom_name = ("k_interp_b" if dom == "interp" else "k_" + dom) if batched else hk_names.get(dom, "k_" + dom)
     M = cfg.quadspec[0] * cfg.quadspec[1]
     n1 = M  # spread grid of this geometry; the batched FFT plan transforms 4 K grids of n1
     # interpolation, per STEP (a step evaluates one or more panels of equal width) and active lag: read r (8) and the
@@ -305,7 +310,21 @@ def main():
             continue
         avg_ms = v["total_ms"] / v["launches"]
         items = v["active_items"] / v["launches"]
-        if k == "interp":
+        if not batched:
+            # fast Hankel transform, per launch: the series terms of one lag level through the fixed spread geometry
+            NT = {8: 6, 10: 8, 12: 10, 14: 13, 16: 16}.get(cfg.nufft_width, 10)  # hk_terms(w), sk_device.h
+            n2 = 2 * n1
+            if k == "interp":    # one level's lags: r, the running sums in and out (the level's share of sum_active)
+                b = 40.0 * 10 * st["sum_active"] / v["launches"]
+            elif k == "spread":  # 3M (strength, node) pairs + positions in; NT terms x 2 rules x n2 complex out
+                b = 24.0 * 3 * M + NT * 2 * n2 * 16.0
+            elif k == "fft":     # NT x 2 grids of n2, read and written once
+                b = 2 * NT * 2 * n2 * 16.0
+            elif k == "gen":
+                b = 48.0 * M + 48.0 * M
+            else:                # near field: O(nodes x sources) Bessel evaluations from an L2-resident source list
+                b = 0.0
+        elif k == "interp":
             b = interp_bytes_total / v["launches"]
         elif k == "gen":
             b = 48.0 * M + 48.0 * M  # read node + weight of both rules (M + 2M) x (8 + 8), write 3M complex strengths
@@ -342,7 +361,12 @@ def main():
                 # an empty kernel, the fused spread launch reduced to its step-state prologue, k_interp reduced to
                 # its state loads (DESIGN.md "Launch floor")
                 "launch_floor_us": floor}
-    if "spread" in roofline["per_kernel"]:
+    if not batched:
+        roofline["note"] = ("dim >= 2: per level of lags one k_spread_multi / rocFFT (batch 2 x series terms) / k_hk_interp "
+                            "triple plus the near-field sums; `kernel` is the launch kind with the largest event time")
+        roofline["per_kernel_share"] = {k: round(acc[k]["total_ms"] / max(1e-12, sum(a["total_ms"] for a in acc.values())), 3)
+                                        for k in acc if acc[k]["launches"]}
+    if "spread" in roofline["per_kernel"] and batched:
         roofline["per_kernel"]["spread"]["launch_floor_us"] = floor.get("spread_prologue_only")
         # north_star: ">= 40 % of the HBM roofline in the NUFFT spread step"
         roofline["per_kernel"]["spread"]["frac"] = round(rl["spread"]["gbps"] / peak, 4)

@@ -250,7 +250,9 @@ int sk_panel_sums(sk_config* cfg, const double* nodes, const double* coef, size_
  * next sk_kernel_values* calls is bracketed by two events.  Kernel ids (SK_K_GEN has no launches on the
  * device-resident dim-1 path, where node generation is fused into the spread launch; SK_K_ADVANCE is the
  * once-per-round status kernel; a config is not thread-safe: one call at a time per sk_config): */
-enum { SK_K_GEN = 0, SK_K_SPREAD = 1, SK_K_FFT = 2, SK_K_INTERP = 3, SK_K_ADVANCE = 4, SK_K_COUNT = 5 };
+enum { SK_K_GEN = 0, SK_K_SPREAD = 1, SK_K_FFT = 2, SK_K_INTERP = 3, SK_K_ADVANCE = 4,
+       SK_K_NEAR = 5, /* dim >= 2: near-field Bessel sums at the Chebyshev nodes (k_hk_near + k_hk_cheb) */
+       SK_K_COUNT = 6 };
 typedef struct {
   double total_ms[SK_K_COUNT]; /* summed over the launches of the last call */
   int64_t launches[SK_K_COUNT];

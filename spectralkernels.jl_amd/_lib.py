@@ -30,11 +30,11 @@ class Stats(C.Structure):
                 ("sum_active_steps", C.c_int64)]
 
 
-K_NAMES = ["gen", "spread", "fft", "interp", "advance"]
+K_NAMES = ["gen", "spread", "fft", "interp", "advance", "near"]
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("total_ms", C.c_double * 5), ("launches", C.c_int64 * 5), ("active_items", C.c_int64 * 5)]
+    _fields_ = [("total_ms", C.c_double * 6), ("launches", C.c_int64 * 6), ("active_items", C.c_int64 * 6)]
 
 
 _lib = None

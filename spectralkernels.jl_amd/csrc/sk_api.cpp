@@ -210,14 +210,15 @@ static const bool g_debug_sync = getenv("SK_DEBUG_SYNC") != nullptr;
 static const bool g_no_fuse = getenv("SK_NO_FUSE") != nullptr;  // diagnostics: separate k_gen and k_spread launches
 static const bool g_no_stream = getenv("SK_NO_STREAM") != nullptr;  // diagnostics: rounds with k_advance throughout
 static const bool g_debug_batch = getenv("SK_DEBUG_BATCH") != nullptr;  // diagnostics: one step per round, every state printed
-static const char* const k_names[SK_K_COUNT] = {"k_gen", "k_spread", "rocfft", "k_interp", "k_advance"};
+static const char* const k_names[SK_K_COUNT] = {"k_gen", "k_spread", "rocfft", "k_interp", "k_advance", "k_hk_near"};
 
 // SK_ROCTX=1: roctx ranges named after the reference's @timeit sections (src/adaptive.jl:156-199,
 // src/quadrature.jl:99-160) around the launches that do their work, for rocprofv3 --marker-trace.  The library is
 // looked up at run time (librocprofiler-sdk-roctx, then libroctx64): no link-time dependency, no cost when off.
 static const char* const k_roctx_names[SK_K_COUNT] = {
     "update quadrature buffers", "FINUFFT call / spread", "FINUFFT call / fft",
-    "FINUFFT call / interpolate + add panels to integral + check convergence", "interval integral / step state"};
+    "FINUFFT call / interpolate + add panels to integral + check convergence", "interval integral / step state",
+    "NUFHT call / near field"};
 struct Roctx {
   int (*push)(const char*) = nullptr;
   int (*pop)() = nullptr;
@@ -444,7 +445,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       }
       hp.edge[0] = r_hi;
       hp.edge[L + 1] = 0.0;
-      launch_hk_near(cfg->dc, db, hp, st);
+      { EvScope e(cfg, st, SK_K_NEAR); launch_hk_near(cfg->dc, db, hp, st); }
       for (int l = 0; l < L; ++l) {
         { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hp.om[l], st); }
         {
@@ -584,7 +585,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     for (auto& r : cfg->ev_recs) {
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, r.a, r.b);
-      if (r.kid == SK_K_ADVANCE || seen[r.kid]++ < worked) {
+      if (r.kid == SK_K_ADVANCE || cfg->dc.dim > 1 || seen[r.kid]++ < worked) {
         cfg->ktimes.total_ms[r.kid] += ms;
         cfg->ktimes.launches[r.kid] += 1;
       }
@@ -594,6 +595,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     cfg->ktimes.active_items[SK_K_FFT] = 2 * cfg->dc.n2 * hs->n_panels;
     cfg->ktimes.active_items[SK_K_INTERP] = hs->sum_active;
     cfg->ktimes.active_items[SK_K_ADVANCE] = hs->n_panels;
+    cfg->ktimes.active_items[SK_K_NEAR] = hs->n_panels;
     cfg->ev_recs.clear();
     cfg->ev_used = 0;
   }

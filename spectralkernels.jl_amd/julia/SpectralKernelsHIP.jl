@@ -112,7 +112,7 @@ end
 
 # mirror of sk_kernel_times
 struct SkKernelTimes
-  total_ms::NTuple{5,Cdouble}; launches::NTuple{5,Int64}; active_items::NTuple{5,Int64}
+  total_ms::NTuple{6,Cdouble}; launches::NTuple{6,Int64}; active_items::NTuple{6,Int64}
 end
 
 # sizeof and field offsets of the three structs as the library this shim was written against compiled them
@@ -120,7 +120,7 @@ end
 # with the library that is actually loaded AND with Julia's own layout of the mirrors.
 const ABI_CONFIG_ARGS = (192, 0, 8, 72, 80, 88, 96, 104, 112, 120, 128, 132, 136, 140, 144, 152, 160, 168, 172, 176, 180, 184)
 const ABI_STATS = (88, 0, 8, 16, 24, 32, 40, 48, 56, 64, 72, 80)
-const ABI_KERNEL_TIMES = (120, 0, 40, 80)
+const ABI_KERNEL_TIMES = (144, 0, 48, 96)
 _jl_layout(T) = (sizeof(T), (Int(fieldoffset(T, i)) for i in 1:fieldcount(T))...)
 function check_abi()
   for (which, T, want) in ((0, SkConfigArgs, ABI_CONFIG_ARGS), (1, SkStats, ABI_STATS), (2, SkKernelTimes, ABI_KERNEL_TIMES))
