@@ -293,3 +293,39 @@ def test_joint_march_with_callback_sdfs(sk, oracle):
               sk.AdaptiveKernelConfig(sk.SDF.matern(*parms), alpha=0.3, logw=True, quadspec=(256, 16)),
               sk.AdaptiveKernelConfig(sk.SDF.matern(2.0, 0.97, 0.89), alpha=0.3, logw=True, quadspec=(256, 16))]
         sk.kernel_values_joint(lw, rs[:10], 1.0)
+
+
+def test_jacobian_pairs_dim2_matches_the_joint_march(sk, oracle):
+    # gen_kernel_jacobian's assembly (src/derivatives.jl:100-111) on the device for the 2-D model of nll_2d.jl: values in
+    # pair order, parameter columns = the joint march's integrands, warping columns = K' x d lag / d warp-parameter
+    par = (1.5, 0.1)
+    prm = (1.0, 1.3, 0.8)
+    g = np.linspace(0.1, 1.0, 4)
+    pts = np.array([(x, y) for y in g for x in g])
+    wpts = np.stack([pts[:, 0] * par[0], pts[:, 0] * pts[:, 1] / par[1]], 1)
+    ii, jj = np.triu_indices(len(pts))
+    pairs = np.stack([ii, jj], 1)
+    lags = np.sqrt(((wpts[ii] - wpts[jj]) ** 2).sum(1))
+    # d lag / d warp-parameter by central differences of the warp (the reference differentiates it with ForwardDiff)
+    dlag = np.zeros((len(pairs), 2))
+    for q in range(2):
+        h = 1e-6 * par[q]
+        pp, pm = list(par), list(par)
+        pp[q] += h
+        pm[q] -= h
+        wl = lambda p: np.sqrt(((np.stack([pts[:, 0] * p[0], pts[:, 0] * pts[:, 1] / p[1]], 1)[ii] -
+                                 np.stack([pts[:, 0] * p[0], pts[:, 0] * pts[:, 1] / p[1]], 1)[jj]) ** 2).sum(1))
+        dlag[:, q] = (wl(pp) - wl(pm)) / (2 * h)
+    f = sk.SDF.matern(*prm, 2)
+    kw = dict(dim=2, tol=1e-10)
+    cfgs = [sk.AdaptiveKernelConfig(f, **kw), sk.AdaptiveKernelConfig(f.d(1), **kw), sk.AdaptiveKernelConfig(f.d(2), **kw),
+            sk.AdaptiveKernelConfig(f, derivative=True, **kw)]
+    k0 = float(oracle.matern_cov(0.0, prm, d=2))
+    vals, jac = sk.kernel_jacobian_pairs(cfgs, [0, 1, 1, 2], [0, 2, 3, 0], wpts, pairs, k0, dlag=dlag, warp_cols=[0, 1], ncols=4)
+    vj, _ = sk.kernel_values_joint(cfgs, lags, k0, param_derivative=[False, True, True, False])
+    assert np.abs(vals - vj[0]).max() <= 1e-12 * k0
+    assert np.abs(jac[:, 2] - vj[1]).max() <= 1e-10 * max(1.0, np.abs(vj[1]).max())
+    assert np.abs(jac[:, 3] - vj[2]).max() <= 1e-10 * max(1.0, np.abs(vj[2]).max())
+    for q in range(2):
+        assert np.abs(jac[:, q] - vj[3] * dlag[:, q]).max() <= 1e-10 * max(1.0, np.abs(vj[3] * dlag[:, q]).max())
+    assert np.abs(vals - oracle.matern_cov(lags, prm, d=2)).max() / k0 <= 10 * 1e-10

@@ -16,7 +16,7 @@ if prm is None:
     from scipy import special
     q = (1 - 0.4) / 2
     prm = (1.0 / (10.0 ** (1 - 0.4 - 2 * 1.0) * special.beta(q, 1.0 - q)), 10.0, 0.5)
-cfg = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), **w["kw"])
+cfg = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), batch_panels=int(os.environ.get("SK_BATCH", "0")), **w["kw"])
 k0 = 1.0 if wl == "C3" else sk.compute_k0(cfg)
 rs = bench.shard_grid(w, 0, 1)
 n = rs.size
@@ -42,6 +42,6 @@ for _ in range(10):
     for k, v in cfg.kernel_times().items():
         a = acc.setdefault(k, [0.0, 0])
         a[0] += v["total_ms"]; a[1] += v["launches"]
-print("%s SK_INTERP=%s: %.4f ms/step, err %s, panels %d, events(us): %s, checksum %.17g" % (
-    wl, os.environ.get("SK_INTERP", "-"), 1e3 * dt, err, st["n_panels"],
+print("%s SK_BATCH=%s: %.4f ms/step, err %s, panels %d, events(us): %s, checksum %.17g" % (
+    wl, os.environ.get("SK_BATCH", "auto"), 1e3 * dt, err, st["n_panels"],
     {k: round(1e3 * a[0] / a[1], 2) for k, a in acc.items() if a[1]}, float(ks.sum())))

@@ -30,6 +30,28 @@ for k, v in summary["pmc_fetch"].items():
                       "write_bytes": w.get("WRITE_SIZE", 0.0) * 1024}
         traffic[k]["hbm_bytes_per_launch"] = traffic[k]["fetch_bytes_corrected"] + traffic[k]["write_bytes"]
 summary["traffic"] = traffic
+# which kernel sources these numbers belong to (bench.py only quotes them for the same sources)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    summary["kernels_sha"] = bench.kernels_sha()
+except Exception as e:  # noqa
+    summary["kernels_sha"] = None
+# dynamic instruction mix of the interpolation kernel per wave (vector issue is what bounds it)
+f64 = pmc("pmc_f64")
+summary["pmc_f64"] = f64
+mix = {}
+for k, v in summary["pmc_sq"].items():
+    if "k_interp_b" in k and v.get("SQ_WAVES"):
+        w = v["SQ_WAVES"]
+        g = f64.get(k, {})
+        wf = g.get("SQ_WAVES", w) or w
+        mix = {"kernel": k, "valu_per_wave": v.get("SQ_INSTS_VALU", 0.0) / w,
+               "fp64_fma_add_mul_per_wave": (g.get("SQ_INSTS_VALU_FMA_F64", 0.0) + g.get("SQ_INSTS_VALU_ADD_F64", 0.0) +
+                                             g.get("SQ_INSTS_VALU_MUL_F64", 0.0)) / wf,
+               "salu_per_wave": g.get("SQ_INSTS_SALU", 0.0) / wf, "smem_per_wave": g.get("SQ_INSTS_SMEM", 0.0) / wf,
+               "lds_per_wave": g.get("SQ_INSTS_LDS", 0.0) / wf}
+summary["interp_instmix"] = mix
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
 print("kernel                                   calls   avg_us    pct")
 for r in summary["kernel_stats"][:14]:
