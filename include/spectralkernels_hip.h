@@ -115,6 +115,8 @@ typedef struct {
   int64_t n_steps;       /* device steps whose panels were applied (a step evaluates 1..batch_panels panels) */
   int64_t n_rerun;       /* steps discarded and re-run with fewer panels (a later panel of the batch was rejected) */
   int64_t sum_active_steps; /* sum over applied steps of active targets: each step reads and writes a lag's sums once */
+  int64_t n_fix;         /* steps whose guessed run was cut short by a retirement at its first panel (outputs of the retired
+                            lags taken from that panel's sums by the next launch) */
 } sk_stats;
 int sk_last_stats(const sk_config* cfg, sk_stats* out);
 

@@ -27,7 +27,7 @@ class Stats(C.Structure):
     _fields_ = [("n_unique", C.c_int64), ("n_outer", C.c_int64), ("n_panels", C.c_int64), ("n_accepted", C.c_int64),
                 ("sum_active", C.c_int64), ("n_steps_launched", C.c_int64), ("n_syncs", C.c_int64),
                 ("last_b", C.c_double), ("n_steps", C.c_int64), ("n_rerun", C.c_int64),
-                ("sum_active_steps", C.c_int64)]
+                ("sum_active_steps", C.c_int64), ("n_fix", C.c_int64)]
 
 
 K_NAMES = ["gen", "spread", "fft", "interp", "advance", "near"]

@@ -574,6 +574,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   stt.n_steps = batched ? hs->n_steps : hs->n_panels;
   stt.n_rerun = batched ? hs->n_rerun : 0;
   stt.sum_active_steps = batched ? hs->sum_active_steps : hs->sum_active;
+  stt.n_fix = batched ? hs->n_fix : 0;
   cfg->trace_len = (size_t)hs->trace_len;
   cfg->trace_valid = false;
   if (cfg->profile) {
@@ -844,6 +845,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   // Panels per batched step: the transforms of a step (4 K of length n1) stay at what one default-rule panel pair
   // costs today (K n1 <= 2^17): two panels per step for the default rule, four for the small rules
   dc.K = args->batch_panels ? args->batch_panels : (dc.n1 > 40000 ? 2 : 4);
+  if (const char* g = getenv("SK_BATCH_GUESS")) dc.guess_mode = !strcmp(g, "always") ? 1 : (!strcmp(g, "never") ? 2 : 0);
   dc.delta = 2.0 / (double)(dc.n1 - dc.w);
   dc.tau_fac = (double)dc.n2 / (double)(dc.n1 - dc.w);
   dc.log2m = -1;
@@ -1561,7 +1563,7 @@ int sk_abi_layout(int which, size_t* out, size_t cap, size_t* len) {
     v.push_back(sizeof(sk_stats));
     F(sk_stats, n_unique); F(sk_stats, n_outer); F(sk_stats, n_panels); F(sk_stats, n_accepted); F(sk_stats, sum_active);
     F(sk_stats, n_steps_launched); F(sk_stats, n_syncs); F(sk_stats, last_b); F(sk_stats, n_steps); F(sk_stats, n_rerun);
-    F(sk_stats, sum_active_steps);
+    F(sk_stats, sum_active_steps); F(sk_stats, n_fix);
   } else if (which == 2) {
     v.push_back(sizeof(sk_kernel_times));
     F(sk_kernel_times, total_ms); F(sk_kernel_times, launches); F(sk_kernel_times, active_items);

@@ -93,6 +93,8 @@ struct DevConst {
   const int4* tiles[2];
   int ntiles[2];
   int K;                        // batched march: most panels per step (1, 2, 4 or 8)
+  int guess_mode;               // 0: runs extended on the certain criterion or the guess; 1: always extended
+                                // (SK_BATCH_GUESS=always: tests drive the re-run and output-fix paths); 2: certain only
 };
 
 // ES-kernel tables (device memory; every workgroup stages them in LDS):
@@ -180,6 +182,7 @@ struct DevState {
   // batched march only (sk_batch_kernels.inc); there conf and pc run over three buffers
   long long n_steps, n_rerun;   // steps whose outcome was applied / discarded for a capped re-run
   long long sum_active_steps;   // sum over applied steps of active lags
+  long long n_fix;              // steps that left an output fix behind (a guessed run cut short at its first panel)
   int spec_ok, fix_conf;        // the last completed outer panel retired nothing; buffer of the pending output fix
   long long fix_lo, fix_hi;     // lags [fix_lo, fix_hi) retired at slot 0 of a longer batch: outputs = sums in fix_conf
   TailScalars fix_tail;         //   + 2 x the truncation bound of that slot (src/adaptive.jl:194)

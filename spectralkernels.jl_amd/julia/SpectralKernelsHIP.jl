@@ -107,7 +107,7 @@ end
 struct SkStats
   n_unique::Int64; n_outer::Int64; n_panels::Int64; n_accepted::Int64; sum_active::Int64
   n_steps_launched::Int64; n_syncs::Int64; last_b::Float64
-  n_steps::Int64; n_rerun::Int64; sum_active_steps::Int64
+  n_steps::Int64; n_rerun::Int64; sum_active_steps::Int64; n_fix::Int64
 end
 
 # mirror of sk_kernel_times
@@ -119,7 +119,7 @@ end
 # (sk_abi_layout; tests/test_host_logic.py compares these tuples with the built library).  check_abi() compares them
 # with the library that is actually loaded AND with Julia's own layout of the mirrors.
 const ABI_CONFIG_ARGS = (192, 0, 8, 72, 80, 88, 96, 104, 112, 120, 128, 132, 136, 140, 144, 152, 160, 168, 172, 176, 180, 184)
-const ABI_STATS = (88, 0, 8, 16, 24, 32, 40, 48, 56, 64, 72, 80)
+const ABI_STATS = (96, 0, 8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88)
 const ABI_KERNEL_TIMES = (144, 0, 48, 96)
 _jl_layout(T) = (sizeof(T), (Int(fieldoffset(T, i)) for i in 1:fieldcount(T))...)
 function check_abi()
@@ -227,7 +227,7 @@ end
 
 # the panel schedule of the last call, printed like print_panel_info / print_panel_convergence (src/utils.jl:12-26)
 function _print_trace(cfg::AdaptiveKernelConfig, n::Integer)
-  st = Ref(SkStats(0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0))
+  st = Ref(SkStats(0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0))
   ccall((:sk_last_stats, LIB), Cint, (Ptr{Cvoid}, Ref{SkStats}), cfg.handle, st)
   println("Reducing $(n) to $(st[].n_unique) unique lags for evaluation...")   # src/adaptive.jl:100
   rec = Matrix{Float64}(undef, 5, 4096); len = Ref{Csize_t}(0)

@@ -1,0 +1,121 @@
+"""The batched march (csrc/sk_batch_kernels.inc) against the one-panel-per-step march of the same kernels
+(batch_panels = 1): grouping panels into launch triples must change neither the panel schedule nor -- beyond the rounding
+of the slots' tiled end points -- the results.  Covers the paths the BASELINE configs do not reach on their own: re-runs
+(a later slot of a run rejected or retiring), the output fix (a guessed run cut short by a retirement at its first panel),
+sibling pairs with the left child rejected, NaN tail fits, the three criteria."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sched(cfg):
+    return [(r["a"], r["b"], bool(r["accepted"]), int(r["n_active"])) for r in cfg.last_trace()]
+
+
+CASES = [
+    # name, sdf kind, params, config kwargs, lags
+    ("c5_like", "matern", (2.14, 0.97, 0.89), dict(tol=1e-12, quadspec=(256, 16)), lambda rng: np.linspace(0.0, 5.1, 3001)),
+    ("c2_like", "matern", (1.0, 1.0, 1.5), dict(quadspec=(256, 16)), lambda rng: 10.0 ** np.linspace(-6, 0, 5000)),
+    ("default_rule", "matern", (1.0, 1.0, 1.5), dict(), lambda rng: 10.0 ** np.linspace(-5, 0, 4000)),
+    ("slow_decay_tails", "matern", (1.0, 0.3, 0.6), dict(tol=1e-6, quadspec=(128, 8), convergence_criteria="tails"),
+     lambda rng: np.sort(rng.uniform(0.0, 3.0, 700))),
+    ("slow_decay_both", "matern", (1.0, 0.3, 0.6), dict(tol=1e-7, quadspec=(128, 8)), lambda rng: np.sort(rng.uniform(0.0, 3.0, 900))),
+    ("panel_criterion", "matern", (2.0, 0.5, 1.2), dict(tol=1e-8, quadspec=(256, 8), convergence_criteria="panel"),
+     lambda rng: np.sort(rng.uniform(0.0, 2.0, 600))),
+    ("narrow_bisect", "matern", (1.0, 1e-3, 1.5), dict(quadspec=(64, 4)), lambda rng: 10.0 ** np.linspace(-4, 0, 300)),
+    ("narrow_bisect_wide_rule", "matern", (1.0, 3e-3, 1.0), dict(tol=1e-9, quadspec=(128, 16)),
+     lambda rng: np.r_[0.0, 10.0 ** rng.uniform(-3, 0.5, 500)]),
+    ("exponential_nan_tail", "exponential", (1.0,), dict(quadspec=(256, 16)), lambda rng: np.linspace(0.0, 5.1, 800)),
+    ("gaussian", "gaussian", (2.0,), dict(tol=1e-10, quadspec=(128, 8)), lambda rng: np.linspace(0.0, 1.5, 500)),
+    ("derivative", "matern", (2.14, 0.97, 1.39), dict(derivative=True, tol=1e-8, quadspec=(256, 16)),
+     lambda rng: np.sort(rng.uniform(0.0, 4.0, 1200))),
+    ("singular", "matern", (2.14, 0.97, 0.89), dict(alpha=0.4, quadspec=(256, 16)), lambda rng: np.linspace(0.0, 1.1, 900)),
+    ("user_tail", "matern", (1.0, 1.0, 0.75), dict(tail=-2.5, tol=1e-7, quadspec=(256, 8)), lambda rng: np.sort(rng.uniform(0, 2, 500))),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_batched_march_equals_the_one_panel_march(sk, oracle, case):
+    name, kind, prm, kw, mk = case
+    rs = mk(np.random.default_rng(3))
+    base = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), batch_panels=1, **kw)
+    k0 = sk.compute_k0(base)
+    k1, e1 = sk.kernel_values(base, rs, k0=k0)
+    s1, st1 = _sched(base), base.last_stats()
+    assert st1["n_steps"] == st1["n_panels"] and st1["n_rerun"] == 0 and st1["n_fix"] == 0
+    seen = dict(rerun=0, fix=0, saved=0)
+    for K in (2, 4, 8):
+        cfg = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), batch_panels=K, **kw)
+        k, e = sk.kernel_values(cfg, rs, k0=k0)
+        st = cfg.last_stats()
+        assert _sched(cfg) == s1, (name, K)                                   # the reference's schedule, panel by panel
+        assert st["n_panels"] == st1["n_panels"] and st["n_outer"] == st1["n_outer"] and st["sum_active"] == st1["sum_active"]
+        assert st["n_steps"] <= st1["n_panels"]
+        a0 = abs(k0)
+        assert np.nanmax(np.abs(k - k1)) <= 2e-13 * a0, (name, K, np.nanmax(np.abs(k - k1)) / a0)
+        assert np.array_equal(np.isnan(e), np.isnan(e1)) and np.nanmax(np.abs(e - e1)) <= 2e-13 * a0 + 1e-6 * np.nanmax(np.abs(e1))
+        seen["rerun"] += st["n_rerun"]
+        seen["fix"] += st["n_fix"]
+        seen["saved"] += st1["n_panels"] - st["n_steps"]
+    print(name, seen, "panels", st1["n_panels"])
+    test_batched_march_equals_the_one_panel_march.seen = getattr(test_batched_march_equals_the_one_panel_march, "seen", {})
+    test_batched_march_equals_the_one_panel_march.seen[name] = seen
+
+
+def test_batching_and_the_output_fix_occurred(sk):
+    # runs after the parametrised cases (file order)
+    seen = getattr(test_batched_march_equals_the_one_panel_march, "seen", {})
+    assert len(seen) == len(CASES)
+    assert sum(s["saved"] for s in seen.values()) > 0
+    assert sum(s["fix"] for s in seen.values()) > 0, seen
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[0] in ("c5_like", "slow_decay_both", "derivative", "user_tail", "gaussian",
+                                                              "panel_criterion", "exponential_nan_tail")],
+                         ids=lambda c: c[0])
+def test_wrong_guesses_are_harmless(sk, case):
+    """SK_BATCH_GUESS=always: every run is extended to the cap whatever the estimate says, so most guesses are wrong --
+    a retirement in the middle of a run re-runs it capped (n_rerun), one at its first panel leaves an output fix
+    (n_fix).  Schedule and results must still be the one-panel march's."""
+    import os
+    name, kind, prm, kw, mk = case
+    rs = mk(np.random.default_rng(3))
+    base = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), batch_panels=1, **kw)
+    k0 = sk.compute_k0(base)
+    k1, e1 = sk.kernel_values(base, rs, k0=k0)
+    s1, st1 = _sched(base), base.last_stats()
+    os.environ["SK_BATCH_GUESS"] = "always"
+    try:
+        tot = dict(rerun=0, fix=0)
+        for K in (2, 4, 8):
+            cfg = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), batch_panels=K, **kw)
+            k, e = sk.kernel_values(cfg, rs, k0=k0)
+            st = cfg.last_stats()
+            assert _sched(cfg) == s1, (name, K)
+            assert st["n_panels"] == st1["n_panels"] and st["sum_active"] == st1["sum_active"]
+            assert np.nanmax(np.abs(k - k1)) <= 2e-13 * abs(k0), (name, K)
+            assert np.array_equal(np.isnan(e), np.isnan(e1)) and np.nanmax(np.abs(e - e1)) <= 2e-13 * abs(k0) + 1e-6 * np.nanmax(np.abs(e1))
+            tot["rerun"] += st["n_rerun"]
+            tot["fix"] += st["n_fix"]
+    finally:
+        del os.environ["SK_BATCH_GUESS"]
+    print(name, tot, "panels", st1["n_panels"])
+    test_wrong_guesses_are_harmless.tot = getattr(test_wrong_guesses_are_harmless, "tot", dict(rerun=0, fix=0))
+    for q in tot:
+        test_wrong_guesses_are_harmless.tot[q] += tot[q]
+
+
+def test_reruns_and_fixes_were_driven(sk):
+    tot = getattr(test_wrong_guesses_are_harmless, "tot", None)
+    assert tot and tot["rerun"] > 0 and tot["fix"] > 0, tot
+
+
+def test_batch_panels_argument(sk):
+    with pytest.raises(sk.SpectralKernelsError):
+        sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5), batch_panels=3)
+    # hosts steps (callback SDFs, dim 2, logw) ignore the setting
+    cb = sk.AdaptiveKernelConfig(lambda w: (1.0 + w * w) ** -2.0, quadspec=(64, 4), sdf="callback", batch_panels=4)
+    ks, _ = sk.kernel_values(cb, np.array([0.1, 0.5, 1.0]), k0=np.pi / 2)
+    rs = np.array([0.1, 0.5, 1.0])
+    assert np.abs(ks - np.pi / 2 * (1 + 2 * np.pi * rs) * np.exp(-2 * np.pi * rs)).max() <= 1e-7
