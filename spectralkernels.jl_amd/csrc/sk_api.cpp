@@ -466,6 +466,55 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     return SK_OK;
   };
 
+  // ---- streaming phase of the batched march.  No round structure: the host keeps ONE step queued behind the running
+  // one (the spread launch of step t reports t + 1 once it has derived its state) and stops when a spread launch
+  // reports "done" -- at most the rest of that one step is launched in vain, and the device never waits for a host
+  // round trip.  Entered after the first step's k_advance (the quick marches end there), or at once when the last
+  // march on this config took more than one step (then that k_advance -- 8-16 us plus a host round trip -- buys nothing).
+  bool flags_up = false;
+  auto stream_rest = [&]() -> int {
+    stream_seq = ++cfg->seq;
+    volatile unsigned int* prog = &cfg->h_status->progress;
+    volatile unsigned int* dseq = &cfg->h_status->done_seq;
+    volatile int* hflags = cfg->h_status->flags;
+    const int t_first = t;
+    *prog = (unsigned int)t;
+    const int depth = 1;  // launched-but-not-started steps: one queued behind the running one
+    unsigned long long spins = 0;
+    for (;;) {
+      while ((unsigned int)t < *prog + (unsigned int)depth && *dseq != stream_seq) {
+        // input of unknown order: the first step's launches scanned the lags; the spread launch of the step after it
+        // reports what they found (with its progress word) -- stop marching on unsorted / invalid input
+        if (check_flags && t_first == 0 && *prog >= 2u && (hflags[0] || hflags[1])) {
+          flags_up = true;
+          break;
+        }
+        int rc2 = eval_pass(SK_G_DEFAULT, nu_main, SK_RAW_NONE, cfg->h_fvals);
+        if (rc2) return rc2;
+        ++t;
+        mode = SK_MODE_TRANSITION;
+        stt.n_steps_launched++;
+      }
+      if (flags_up || *dseq == stream_seq) break;
+      if ((++spins & 0x3fff) == 0) {
+        hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess && *dseq != stream_seq && *prog + (unsigned int)depth <= (unsigned int)t)
+          return fail(SK_EHIP, "device finished without reporting progress");
+        if (q != hipSuccess && q != hipErrorNotReady) return fail(SK_EHIP, std::string("HIP error: ") + hipGetErrorString(q));
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    cfg->stats.n_syncs++;
+    if (cfg->h_status->flags[1] & 2) return fail(SK_EHIP, "internal error: inconsistent device state detected by a kernel guard");
+    if (!flags_up && check_flags && (cfg->h_status->flags[0] || cfg->h_status->flags[1])) flags_up = true;
+    if (flags_up) HIPCHK(hipStreamSynchronize(st));  // the queued step must not run into the caller's sort
+    return SK_OK;
+  };
+  if (batched && !g_no_stream && !g_debug_batch && cfg->last_n_steps >= 2) {
+    int rcs = stream_rest();
+    if (rcs) return rcs;
+    if (flags_up) return SK_OK;
+  } else
   for (;;) {
     bool lw_first = false;
     if (host_step) {
@@ -526,36 +575,9 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       mode = SK_MODE_ASIS;
       R = g_debug_batch ? 1 : (R < 16 ? 2 * R : 16);
       if (batched && !g_no_stream && !g_debug_batch) {
-        // ---- streaming phase.  The first step (one or two panels) is all that the quick cases need, and its
-        // k_advance told us so.  From here on no round structure: the host keeps ONE step queued behind the running
-        // one (the spread launch of step t reports t + 1 once it has derived its state) and stops when a spread launch
-        // reports "done" -- at most the rest of that one step is launched in vain, and the device never waits for a
-        // host round trip.
-        stream_seq = ++cfg->seq;
-        volatile unsigned int* prog = &cfg->h_status->progress;
-        volatile unsigned int* dseq = &cfg->h_status->done_seq;
-        *prog = (unsigned int)t;
-        const int depth = 1;  // launched-but-not-started steps: one queued behind the running one
-        unsigned long long spins = 0;
-        for (;;) {
-          while ((unsigned int)t < *prog + (unsigned int)depth && *dseq != stream_seq) {
-            int rc2 = eval_pass(SK_G_DEFAULT, nu_main, SK_RAW_NONE, cfg->h_fvals);
-            if (rc2) return rc2;
-            ++t;
-            mode = SK_MODE_TRANSITION;
-            stt.n_steps_launched++;
-          }
-          if (*dseq == stream_seq) break;
-          if ((++spins & 0x3fff) == 0) {
-            hipError_t q = hipStreamQuery(st);
-            if (q == hipSuccess && *dseq != stream_seq && *prog + (unsigned int)depth <= (unsigned int)t)
-              return fail(SK_EHIP, "device finished without reporting progress");
-            if (q != hipSuccess && q != hipErrorNotReady) return fail(SK_EHIP, std::string("HIP error: ") + hipGetErrorString(q));
-          }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        cfg->stats.n_syncs++;
-        if (cfg->h_status->flags[1] & 2) return fail(SK_EHIP, "internal error: inconsistent device state detected by a kernel guard");
+        int rcs = stream_rest();
+        if (rcs) return rcs;
+        if (flags_up) return SK_OK;
         break;
       }
     }
@@ -575,6 +597,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   stt.n_rerun = batched ? hs->n_rerun : 0;
   stt.sum_active_steps = batched ? hs->sum_active_steps : hs->sum_active;
   stt.n_fix = batched ? hs->n_fix : 0;
+  if (batched) cfg->last_n_steps = hs->n_steps + hs->n_rerun;
   cfg->trace_len = (size_t)hs->trace_len;
   cfg->trace_valid = false;
   if (cfg->profile) {

@@ -119,3 +119,38 @@ def test_batch_panels_argument(sk):
     ks, _ = sk.kernel_values(cb, np.array([0.1, 0.5, 1.0]), k0=np.pi / 2)
     rs = np.array([0.1, 0.5, 1.0])
     assert np.abs(ks - np.pi / 2 * (1 + 2 * np.pi * rs) * np.exp(-2 * np.pi * rs)).max() <= 1e-7
+
+
+def test_repeated_calls_stream_from_the_first_step(sk, oracle):
+    """A config whose last march took several steps skips the k_advance after step 0 and streams from the start (the
+    spread launches report progress, input flags and the end themselves).  Same results, schedule and statistics as the
+    first call; unsorted or invalid input is still found out (one step later) and handled."""
+    parms = (2.14, 0.97, 0.89)
+    rs = np.linspace(0.0, 5.1, 4000)
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(*parms), tol=1e-10, quadspec=(256, 16))
+    k0 = float(oracle.matern_cov(0.0, parms))
+    d_rs, d_k, d_e = sk.DeviceArray.from_host(rs), sk.DeviceArray(rs.size), sk.DeviceArray(rs.size)
+    sk.kernel_values_device(cfg, d_rs.ptr, rs.size, k0, d_k.ptr, d_e.ptr)
+    k_first, st_first, tr_first = d_k.to_host(), cfg.last_stats(), _sched(cfg)
+    assert st_first["n_steps"] >= 2 and st_first["n_syncs"] == 2          # k_advance after step 0, then streaming
+    for _ in range(3):
+        sk.kernel_values_device(cfg, d_rs.ptr, rs.size, k0, d_k.ptr, d_e.ptr)
+        st = cfg.last_stats()
+        assert st["n_syncs"] == 1 and st["n_steps_launched"] <= st["n_steps"] + 2  # streamed from step 0
+        assert np.array_equal(d_k.to_host(), k_first) and _sched(cfg) == tr_first
+        assert all(st[q] == st_first[q] for q in ("n_panels", "n_outer", "n_steps", "sum_active"))
+    assert np.abs(k_first - oracle.matern_cov(rs, parms)).max() / k0 <= 10 * 1e-10
+    # device-resident input of unknown order on the streaming path: permuted with duplicates, then an invalid lag
+    rng = np.random.default_rng(1)
+    xs = np.r_[rs[rng.permutation(rs.size)], rs[:100]]
+    d_x, d_k2, d_e2 = sk.DeviceArray.from_host(xs), sk.DeviceArray(xs.size), sk.DeviceArray(xs.size)
+    sk.kernel_values_device(cfg, d_x.ptr, xs.size, k0, d_k2.ptr, d_e2.ptr)
+    assert cfg.last_stats()["n_unique"] == rs.size
+    assert np.abs(d_k2.to_host() - oracle.matern_cov(xs, parms)).max() / k0 <= 10 * 1e-10
+    bad = xs.copy()
+    bad[17] = -1.0
+    d_b = sk.DeviceArray.from_host(bad)
+    with pytest.raises(sk.SpectralKernelsError):
+        sk.kernel_values_device(cfg, d_b.ptr, bad.size, k0, d_k2.ptr, d_e2.ptr)
+    sk.kernel_values_device(cfg, d_rs.ptr, rs.size, k0, d_k.ptr, d_e.ptr)   # and the config is fine afterwards
+    assert np.array_equal(d_k.to_host(), k_first)
