@@ -154,3 +154,23 @@ def test_repeated_calls_stream_from_the_first_step(sk, oracle):
         sk.kernel_values_device(cfg, d_b.ptr, bad.size, k0, d_k2.ptr, d_e2.ptr)
     sk.kernel_values_device(cfg, d_rs.ptr, rs.size, k0, d_k.ptr, d_e.ptr)   # and the config is fine afterwards
     assert np.array_equal(d_k.to_host(), k_first)
+
+
+def test_launch_floor_probe_is_safe_on_any_config_state(sk):
+    """sk_launch_floor launches the march's kernels on a "done" state; the interpolation kernels read the lag
+    array ahead of the state, so the probe brings lags of its own.  Fresh config (no call yet), after a tiny call, after
+    a call on other lags, batched and callback configs: no fault, sane numbers, and the config still works."""
+    rs = 10.0 ** np.linspace(-4, 0, 50)
+    for mk in (lambda: sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5), quadspec=(256, 16)),
+               lambda: sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5)),
+               lambda: sk.AdaptiveKernelConfig(lambda w: (1.0 + w * w) ** -2.0, quadspec=(64, 4), sdf="callback")):
+        cfg = mk()
+        f0 = cfg.launch_floor(reps=3)            # before any kernel_values call
+        ks, _ = sk.kernel_values(cfg, rs[:3], k0=np.pi / 2)   # a tiny call: the last lag array is 3 doubles long
+        f1 = cfg.launch_floor(reps=3)
+        ks2, _ = sk.kernel_values(cfg, rs, k0=np.pi / 2)
+        f2 = cfg.launch_floor(reps=3)
+        for f in (f0, f1, f2):
+            assert all(0.5 < v < 200.0 for v in f.values()), f
+        assert np.abs(ks2 - np.pi / 2 * (1 + 2 * np.pi * rs) * np.exp(-2 * np.pi * rs)).max() <= 1e-7
+        assert np.array_equal(ks, ks2[:3]) or np.abs(ks - ks2[:3]).max() <= 1e-8
