@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 SOURCES = ["sk_api.cpp", "sk_hostio.cpp", "sk_shard.cpp", "sk_joint.cpp", "sk_kernels.hip", "sk_rules.cpp", "sk_tables.cpp", "sk_k0.cpp"]
-HEADERS = ["sk_device.h", "sk_internal.h", "sk_config.h", "sk_joint_kernels.inc", "sk_batch_kernels.inc", "sk_lean_math.h", os.path.join("..", "..", "include", "spectralkernels_hip.h")]
+HEADERS = ["sk_device.h", "sk_internal.h", "sk_config.h", "sk_joint_kernels.inc", "sk_batch_kernels.inc", "sk_hankel_inner.inc", "sk_lean_math.h", os.path.join("..", "..", "include", "spectralkernels_hip.h")]
 LIB = os.path.join(HERE, "libspectralkernels_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-munsafe-fp-atomics", "-Wno-unused-value",
          "-Wno-pass-failed"]

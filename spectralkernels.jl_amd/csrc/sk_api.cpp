@@ -428,6 +428,114 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       hp.pb = pb;
       int L = 0;
       while (L < kHkMaxLevels - 1 && kHkZ0 * std::pow(kHkBeta, L + 1) / (2.0 * M_PI * r_hi) < pb) ++L;
+      // ---- by boxes (sk_hankel_inner.inc): one NUFFT triple for the lags above r_c = r_hi / 8^l, a directly summed
+      // near box for the few sources below om0 there, the inner box (all sources, lags up to r_c) by moments.  l from
+      // a cost model in Bessel evaluations; the lag counts per power of 8 come from k_advance.  Falls back to the level
+      // split when a step does not fit the buffers.
+      HkInner hin;
+      std::memset(&hin, 0, sizeof(hin));
+      bool boxes = false;
+      if (cfg->hk_nb > 0) {
+        auto n_of_z = [](double z) { return std::ceil(z + 9.0 * std::cbrt(z) + 14.0); };
+        const double pa = hs->pp.pa;
+        const long long nact = hs->hi - hs->ix1;
+        hin.nu = nu;
+        hin.pa = pa;
+        hin.pb = pb;
+        hin.r_hi = r_hi;
+        hin.lag_lo = hs->ix1;
+        hin.escale = (raw == SK_RAW_NONE && cfg->dc.dim > 2) ? cfg->dc.dim * 0.5 - 1.0 : 0.0;
+        // bands of the inner box for a given r_c: the fewest (divisors of k) with at most ~400 moments each
+        auto bands_for = [&](double r_c, int& nb, int& ngm) {
+          nb = 0;
+          for (int d = 1; d <= (int)cfg->k; ++d) {
+            if (cfg->k % d) continue;
+            const int ng = (int)n_of_z(M_PI * (pb - pa) / d * r_c) + 2;
+            if (ng > cfg->hk_ngmax) continue;
+            nb = d;
+            ngm = ng;
+            if (ng <= 400) break;
+          }
+          return nb > 0;
+        };
+        if (L == 0) {  // no far field: the whole panel is one smooth box
+          int nb, ngm;
+          const double qd = std::ceil(M_PI * pb * r_hi / 96.0);
+          if (bands_for(r_hi, nb, ngm) && qd <= (double)kHkQCap) {
+            hin.has_far = 0; hin.r_c = r_hi; hin.nb = nb; hin.ngm = ngm;
+            hin.Q = qd < 1.0 ? 1 : (int)qd;
+            hin.lag_cnt = nact;
+            boxes = true;
+          }
+        } else {
+          double best = INFINITY;
+          for (int l = 1; l < kHkMaxLevels; ++l) {
+            const double beta = std::pow(kHkBeta, l), r_c = r_hi / beta;
+            const double om0 = kHkZ0 * beta / (2.0 * M_PI * r_hi);
+            if (om0 >= pb) break;  // nothing left for the series
+            const double fnear = om0 <= pa ? 0.0 : (om0 - pa) / (pb - pa);
+            const double qn = fnear > 0.0 ? std::ceil(M_PI * om0 * (r_hi - r_c) / 96.0) : 0.0;
+            double cost = 3.0 * (double)cfg->M * fnear * qn * kHkNodes;
+            const long long icnt = cfg->h_status->lvl_cnt[l];
+            int nb = 1, ngm = 0;
+            double qi = 0.0;
+            if (icnt > 0) {
+              if (!bands_for(r_c, nb, ngm)) continue;
+              qi = std::max(1.0, std::ceil(M_PI * pb * r_c / 96.0));
+              const double zb = M_PI * (pb - pa) / nb * r_c;
+              cost += qi * kHkNodes * 2.0 * nb * n_of_z(0.5 * zb) + 3.0 * (double)cfg->M * ngm / 22.0 + qi * 2.0 * nb * ngm * ngm / 110.0;
+            }
+            if (qn + qi > (double)kHkQCap) continue;
+            if (cost < best) {
+              best = cost;
+              hin.has_far = 1; hin.r_c = r_c; hin.om0 = om0; hin.nb = nb; hin.ngm = ngm;
+              hin.Qn = (int)qn; hin.Q = (int)qi;
+              hin.lag_cnt = icnt;
+              boxes = true;
+            }
+          }
+        }
+        if (boxes) {
+          hin.gs = (int)cfg->k / hin.nb;
+          hin.ell = hin.Q > 0 ? hin.r_c / (double)hin.Q : hin.r_c;
+          hin.elln = hin.Qn > 0 ? (r_hi - hin.r_c) / (double)hin.Qn : r_hi;
+          const int qtot = hin.Q + hin.Qn;
+          if (qtot > cfg->hk_qalloc) {  // grow the interval buffers (rare: the counts grow with the panel index)
+            int qa = cfg->hk_qalloc ? cfg->hk_qalloc : 64;
+            while (qa < qtot) qa *= 2;
+            HIPCHK(hipStreamSynchronize(st));
+            if (cfg->hk_qbuf) HIPCHK(hipFree(cfg->hk_qbuf));
+            cfg->hk_qbuf = nullptr;
+            cfg->hk_qalloc = 0;
+            const size_t wb = sizeof(double2) * (size_t)qa * 2 * cfg->hk_ngmax * 4;  // nb x ngm <= 4 hk_ngmax (see below)
+            const size_t vb = sizeof(double) * (size_t)qa * 2 * kHkNodes;
+            HIPCHK(hipMalloc(&cfg->hk_qbuf, wb + 2 * vb));
+            cfg->hk_qalloc = qa;
+            db.hk_w = (double2*)cfg->hk_qbuf;
+            db.hk_v = (double*)((char*)cfg->hk_qbuf + wb);
+            db.hk_c2 = (double*)((char*)cfg->hk_qbuf + wb + vb);
+          }
+          if ((size_t)hin.nb * hin.ngm > (size_t)4 * cfg->hk_ngmax) boxes = false;  // equivalent sources per interval the buffer holds
+        }
+      }
+      if (boxes) {
+        { EvScope e(cfg, st, SK_K_NEAR); launch_hk_boxes(cfg->dc, db, hin, st); }
+        if (hin.has_far) {
+          { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, st); }
+          {
+            EvScope e(cfg, st, SK_K_FFT);
+            FFTCHK(rocfft_execution_info_set_stream(cfg->info_hk, st));
+            void* in[1] = {db.hk_fft};
+            FFTCHK(rocfft_execute(cfg->plan_hk, in, nullptr, cfg->info_hk));
+          }
+          { EvScope e(cfg, st, SK_K_INTERP); launch_hk_far(cfg->dc, cfg->d_ec, db, hin, hp.a, t & 1, n, raw, st); }
+        }
+        if (hin.lag_cnt > 0) {
+          EvScope e(cfg, st, SK_K_NEAR);
+          launch_hk_iinterp(cfg->dc, db, hin, t & 1, n, raw, st);
+        }
+        return SK_OK;
+      }
       // level planning with the lag counts k_advance published: a level (and everything inside it) with at most
       // kHkNodes lags becomes the innermost one and is summed directly at those lags
       for (int l = 0; l <= L; ++l)
@@ -439,6 +547,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
           break;
         }
       hp.L = L;
+      hp.near_levels = L + 1;
       for (int l = 0; l <= L; ++l) {
         hp.edge[l] = r_hi / std::pow(kHkBeta, l);
         hp.om[l] = (l < L) ? kHkZ0 * std::pow(kHkBeta, l + 1) / (2.0 * M_PI * r_hi) : INFINITY;
@@ -1039,6 +1148,41 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     }
     cfg->owned.push_back(p2); cfg->owned.push_back(p3); cfg->owned.push_back(p4);
     db.hk_fft = (double2*)p2; db.hk_nodes = (double*)p3; db.hk_cheb = (double*)p4;
+    {
+      // exact-cosine DCT table of the kHkNodes-point Chebyshev transforms: cos(pi j / (2 N)) with j = m (2 i + 1) mod 4 N
+      // in integer arithmetic, then the node abscissae cos(pi (2 i + 1) / (2 N))
+      std::vector<double> tab((size_t)kHkNodes * kHkNodes + kHkNodes);
+      auto ctab = [](int j) {
+        j %= 4 * kHkNodes;
+        if (j > 2 * kHkNodes) j = 4 * kHkNodes - j;
+        return j == kHkNodes ? 0.0 : std::cos(M_PI * (double)j / (2.0 * kHkNodes));
+      };
+      for (int i = 0; i < kHkNodes; ++i)
+        for (int mm = 0; mm < kHkNodes; ++mm) tab[(size_t)i * kHkNodes + mm] = ctab(mm * (2 * i + 1));
+      for (int i = 0; i < kHkNodes; ++i) tab[(size_t)kHkNodes * kHkNodes + i] = ctab(2 * i + 1);
+      void* p5 = nullptr;
+      if (hipMalloc(&p5, tab.size() * sizeof(double)) != hipSuccess ||
+          hipMemcpy(p5, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        sk_config_destroy(cfg);
+        return fail(SK_EHIP, "hipMalloc(Hankel tables) failed");
+      }
+      cfg->owned.push_back(p5);
+      db.hk_dct = (double*)p5;
+    }
+    if (!std::getenv("SK_HK_LEVELS")) {
+      // inner box (sk_hankel_inner.inc): partial moments of every source wave; the bands are chosen per step
+      cfg->hk_nb = 1;
+      cfg->hk_ngmax = kHkNgCap;
+      void* p6 = nullptr;
+      const size_t npart = (size_t)(3 * cfg->M / 256 + 2 * cfg->k + 2), nmom = (size_t)2 * cfg->k;
+      if (hipMalloc(&p6, sizeof(double) * (npart + nmom) * cfg->hk_ngmax) != hipSuccess) {
+        sk_config_destroy(cfg);
+        return fail(SK_EHIP, "hipMalloc(Hankel moments) failed");
+      }
+      cfg->owned.push_back(p6);
+      db.hk_mpart = (double*)p6;
+      db.hk_mom = (double*)p6 + npart * cfg->hk_ngmax;
+    }
     const int nu = args->derivative ? args->dim / 2 : args->dim / 2 - 1;
     cfg->hk_a[0] = 1.0;
     for (int kq = 1; kq < kHkTerms; ++kq)
@@ -1080,6 +1224,7 @@ void sk_config_destroy(sk_config* cfg) {
   if (cfg->h_out) hipHostFree(cfg->h_out);
   if (cfg->d_aux) hipFree(cfg->d_aux);
   if (cfg->d_joint) hipFree(cfg->d_joint);
+  if (cfg->hk_qbuf) hipFree(cfg->hk_qbuf);
   if (cfg->d_jfv) hipFree(cfg->d_jfv);
   if (cfg->h_jfv) hipHostFree(cfg->h_jfv);
   for (int q = 0; q <= kJointTr; ++q) {

@@ -35,6 +35,26 @@ struct HankelPlan {
   int direct_inner;
   long long inner_lo, inner_cnt;
   double pa, pb;               // the (sub)panel, for bounding the near prefix by whole sub-panels
+  int near_levels;             // levels k_hk_near / k_hk_cheb cover: L + 1, or L when the inner region (HkInner) takes the rest
+};
+
+// The Hankel path by boxes (sk_hankel_inner.inc): per panel one asymptotic-series NUFFT for the lags (r_c, r_hi] and
+// the sources w >= om0 (z >= kHkZ0 there), and two smooth boxes of the kernel J_nu(2 pi w r):
+//   near box   sources w < om0 (a prefix of the sorted sources; none once the panel starts beyond om0) at the lags
+//              (r_c, r_hi]: Qn lag intervals of length elln, direct sums at kHkNodes Chebyshev nodes each;
+//   inner box  all sources at the lags (0, r_c]: Chebyshev moments of the sources in `nb` bands of `gs` sub-panels
+//              (`ngm` per band), Q lag intervals of length ell.
+constexpr int kHkNgCap = 1024;   // most moments per band (LDS of k_hk_eqw)
+constexpr int kHkQCap = 2048;    // most lag intervals of both boxes together
+struct HkSeries { double a[kHkTerms]; double cs, sn; };  // asymptotic coefficients a_k(nu); cos, sin of (2 nu + 1) pi / 4
+struct HkInner {
+  int nu, nb, gs, Q, ngm;
+  int Qn;                      // near box intervals (0: no near sources, or no far field at all)
+  int has_far;                 // 0: the whole panel is one smooth box (r_c = r_hi, no NUFFT)
+  double escale;               // exponent e of the r^-e factor folded into the node values (dim/2 - 1; 0 in the raw passes)
+  double r_c, ell, pa, pb;
+  double om0, elln, r_hi;
+  long long lag_lo, lag_cnt;   // the inner lags: indices [lag_lo, lag_lo + lag_cnt) of the sorted lag array
 };
 
 // Joint march of several integrands on one lag set (sk_kernel_values_joint; src/derivatives.jl:51-112 calls
@@ -251,6 +271,12 @@ struct DevBuffers {
   double2* hk_fft;          // kHkTerms x 2 x n2 complex grids of the current level
   double* hk_nodes;         // (kHkMaxLevels+1) x 2 x kHkNodes x kHkSplit partial near sums at the Chebyshev nodes
   double* hk_cheb;          // same shape: Chebyshev coefficients
+  double* hk_dct;           // kHkNodes x kHkNodes exact-cosine DCT table [node][coefficient], then the kHkNodes node abscissae
+  double* hk_mpart;         // inner box: per workgroup of k_hk_moments, ngm partial Chebyshev moments
+  double* hk_mom;           // 2 x nb x ngm moments
+  double2* hk_w;            // Q x 2 x nb x ngm equivalent sources (weight, node w) of the inner box
+  double* hk_v;             // (Qn + Q) x 2 x kHkNodes node values: near box intervals, then inner box intervals
+  double* hk_c2;            // the same shape: Chebyshev coefficients in r
   // logw first-panel passes (src/quadrature.jl:186-228): raw panel sums A (rules 1, 2) then B (rules 1, 2), n each
   double* lw_raw;
   // batched march: running sums / outer-panel partial sums over three buffers each (confirmed, after slot 0, after the
@@ -275,6 +301,11 @@ void launch_lw_finish(const DevConst& dc, const DevBuffers& db, int slot, long l
 // far sources (w >= om) of one level: all series terms spread in one launch
 void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, double om, hipStream_t st);
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st);
+void launch_hk_boxes(const DevConst& dc, const DevBuffers& db, const HkInner& hi, hipStream_t st);
+void launch_hk_far(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HkInner& hi, const double* a, int slot,
+                   long long n, int raw, hipStream_t st);
+void launch_hk_iinterp(const DevConst& dc, const DevBuffers& db, const HkInner& hi, int slot, long long n, int raw, hipStream_t st);
+int hk_inner_waves(const DevConst& dc, int nb);
 void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HankelPlan& hp, int level, int slot,
                       long long n, int raw, hipStream_t st);
 void launch_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, int raw, hipStream_t st);

@@ -1805,7 +1805,7 @@ __global__ void __launch_bounds__(256) k_hk_near(DevConst dc, DevBuffers db, Han
   const int level = bid / (2 * kHkNodes);
   const double hi_r = hp.edge[level], lo_r = hp.edge[level + 1];
   const double half = 0.5 * (hi_r - lo_r), mid = 0.5 * (hi_r + lo_r);
-  double r = mid + half * cospi((node + 0.5) / (double)kHkNodes);
+  double r = mid + half * db.hk_dct[kHkNodes * kHkNodes + node];
   const int64_t M = dc.M, cnt = rule ? 2 * M : M;
   int64_t lim = cnt;      // sources [0, lim) are shared out over `nsp` workgroups, this one is number `sp`
   int nsp = kHkSplit, sp = split;
@@ -1864,9 +1864,11 @@ __global__ void __launch_bounds__(kHkNodes) k_hk_cheb(DevBuffers db, int direct_
     return;
   }
   __syncthreads();
+  // exact-cosine table (sk_config_create): cospi of the rounded product m (i + 1/2) / N lifts the coefficient tail
+  // to 1e-14 of the sum (tools/proto_hankel_inner.py), and 160 cospi per thread were 22 us of latency
   const int mth = threadIdx.x;
   double acc = 0.0;
-  for (int sidx = 0; sidx < kHkNodes; ++sidx) acc = fma(f[sidx], cospi((double)mth * (sidx + 0.5) / (double)kHkNodes), acc);
+  for (int sidx = 0; sidx < kHkNodes; ++sidx) acc = fma(f[sidx], db.hk_dct[sidx * kHkNodes + mth], acc);
   db.hk_cheb[(int64_t)blockIdx.x * kHkNodes + mth] = acc * (mth == 0 ? 1.0 : 2.0) / (double)kHkNodes;
 }
 
@@ -2005,6 +2007,9 @@ __global__ void __launch_bounds__(256) k_hk_interp(DevConst dc, const EsConst* e
 
 // ------------------------------------------------------------------ launchers
 
+static inline unsigned nblk(long long n, int bs);
+#include "sk_hankel_inner.inc"
+
 static inline unsigned nblk(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 
@@ -2063,9 +2068,28 @@ void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& d
                                          slot, om));
 }
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st) {
-  hipLaunchKernelGGL(k_hk_near, dim3((unsigned)((hp.L + 1) * 2 * kHkNodes * kHkSplit)), dim3(256), 0, st, dc, db, hp);
-  hipLaunchKernelGGL(k_hk_cheb, dim3((unsigned)((hp.L + 1) * 2)), dim3(kHkNodes), 0, st, db, hp.direct_inner ? hp.L : -1,
+  if (hp.near_levels <= 0) return;
+  hipLaunchKernelGGL(k_hk_near, dim3((unsigned)(hp.near_levels * 2 * kHkNodes * kHkSplit)), dim3(256), 0, st, dc, db, hp);
+  hipLaunchKernelGGL(k_hk_cheb, dim3((unsigned)(hp.near_levels * 2)), dim3(kHkNodes), 0, st, db, hp.direct_inner ? hp.L : -1,
                      hp.inner_cnt);
+}
+void launch_hk_far(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HkInner& hi, const double* a, int slot,
+                   long long n, int raw, hipStream_t st) {
+  HkSeries ser;
+  for (int k = 0; k < kHkTerms; ++k) ser.a[k] = a[k];
+  const int q8 = (2 * hi.nu + 1) & 7;  // (2 nu + 1) pi / 4: exact octant values
+  const double h = 0.70710678118654752440;
+  const double c8[8] = {1, h, 0, -h, -1, -h, 0, h}, s8[8] = {0, h, 1, h, 0, -h, -1, -h};
+  ser.cs = c8[q8];
+  ser.sn = s8[q8];
+  // grid: the lags above r_c; the kernel leaves where its block starts beyond the active set
+  const long long cnt = n - (hi.lag_lo + hi.lag_cnt);
+  if (cnt <= 0) return;
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_hk_far<W>, dim3(nblk(cnt, 256)), dim3(256), 0, st, dc, ec, db, hi, ser, slot, n, raw));
+}
+void launch_hk_iinterp(const DevConst& dc, const DevBuffers& db, const HkInner& hi, int slot, long long n, int raw, hipStream_t st) {
+  if (hi.lag_cnt > 0)
+    hipLaunchKernelGGL(k_hk_iinterp, dim3(nblk(hi.lag_cnt, 256)), dim3(256), 0, st, dc, db, hi, slot, n, raw);
 }
 void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HankelPlan& hp, int level, int slot,
                       long long n, int raw, hipStream_t st) {

@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
 python3 - "$f" > $OUT/stats.txt <<'PY'
 import csv, sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:16]:
+for r in list(csv.DictReader(open(sys.argv[1])))[:24]:
     print("%-70s calls %5s avg_us %9.2f total_ms %8.2f pct %s" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
 PY
 cat $OUT/run.log | tail -4; cat $OUT/stats.txt
