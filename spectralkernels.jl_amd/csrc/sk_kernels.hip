@@ -62,6 +62,33 @@ __device__ __forceinline__ double2 cis_turns_prod(double a, double b) {
   return cis_turns_small(fr + e);
 }
 
+// J_nu(x) / (x/2)^nu for |x| < 2, nu >= 0: the ascending series sum_k (-x^2/4)^k / (k! (k+nu)!) (14 terms: 1e-17).
+__device__ __forceinline__ double bessel_series_scaled(int nu, double x) {
+  double t = 1.0;
+  for (int q = 2; q <= nu; ++q) t /= (double)q;  // 1 / nu!
+  const double h = -0.25 * x * x;
+  double sum = t;
+#pragma unroll
+  for (int k = 1; k <= 14; ++k) {
+    t *= h / ((double)k * (double)(k + nu));
+    sum += t;
+  }
+  return sum;
+}
+// J_nu(x), integer nu >= 0.  The library's jn reaches orders >= 2 by forward recurrence from J_0 and J_1: below x ~ nu
+// that is accurate in absolute terms only (J_2(1e-3) = 1.25e-7 comes out of 1 - 1), and the isotropic kernels of dim >= 6
+// divide by r^(dim/2-1) afterwards.  The reference's besselj is accurate in relative terms; so is this.
+__device__ __forceinline__ double bessel_j(int nu, double x) {
+  if (nu == 0) return j0(x);
+  if (nu == 1) return j1(x);
+  if (fabs(x) < 2.0) {
+    double p = 0.5 * x, pw = p;
+    for (int q = 1; q < nu; ++q) pw *= p;
+    return pw * bessel_series_scaled(nu, x);
+  }
+  return jn(nu, x);
+}
+
 // ---- wave-wide maxima of non-negative values through DPP.  __shfl_xor is a ds_bpermute per dword (the LDS pipe, a
 // round trip and a wait per butterfly step) plus the lane-index arithmetic: ~9 vector instructions per step for a
 // double.  The DPP row operations below move a dword between lanes inside the VALU: 3 instructions per step
@@ -1740,7 +1767,7 @@ __global__ void __launch_bounds__(256) k_bessel(DevConst dc, DevBuffers db, int 
         for (int t = part; t < TS; t += 4) {
           const double2 cw = s_src[t];
           const double x = tw * cw.y;
-          const double jv = (nu == 0) ? j0(x) : ((nu == 1) ? j1(x) : jn(nu, x));
+          const double jv = bessel_j(nu, x);
           a = fma(cw.x, jv, a);
         }
       }
@@ -1838,7 +1865,7 @@ __global__ void __launch_bounds__(256) k_hk_near(DevConst dc, DevBuffers db, Han
     const double2 cw = src[j];
     if (!(cw.y < om)) break;  // sources are sorted by w: the near set is a prefix
     const double x = tw * cw.y;
-    const double jv = (hp.nu == 0) ? j0(x) : ((hp.nu == 1) ? j1(x) : jn(hp.nu, x));
+    const double jv = bessel_j(hp.nu, x);
     acc = fma(cw.x, jv, acc);
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
