@@ -208,6 +208,7 @@ static hipEvent_t ev_get(sk_config* cfg) {
 // GPU fault can be attributed to a kernel (diagnostics only; serialises the pipeline).
 static const bool g_debug_sync = getenv("SK_DEBUG_SYNC") != nullptr;
 static const bool g_no_fuse = getenv("SK_NO_FUSE") != nullptr;  // diagnostics: separate k_gen and k_spread launches
+static const bool g_hk_serial = getenv("SK_HK_SERIAL") != nullptr;  // diagnostics: Hankel boxes on the march's stream
 static const bool g_no_stream = getenv("SK_NO_STREAM") != nullptr;  // diagnostics: rounds with k_advance throughout
 static const bool g_debug_batch = getenv("SK_DEBUG_BATCH") != nullptr;  // diagnostics: one step per round, every state printed
 static const char* const k_names[SK_K_COUNT] = {"k_gen", "k_spread", "rocfft", "k_interp", "k_advance", "k_hk_near"};
@@ -440,6 +441,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         const double pa = hs->pp.pa;
         const long long nact = hs->hi - hs->ix1;
         hin.nu = nu;
+        hk_series_fill(hin.ser, hp.a, nu);
         hin.pa = pa;
         hin.pb = pb;
         hin.r_hi = r_hi;
@@ -483,7 +485,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
               if (!bands_for(r_c, nb, ngm)) continue;
               qi = std::max(1.0, std::ceil(M_PI * pb * r_c / 96.0));
               const double zb = M_PI * (pb - pa) / nb * r_c;
-              cost += qi * kHkNodes * 2.0 * nb * n_of_z(0.5 * zb) + 3.0 * (double)cfg->M * ngm / 22.0 + qi * 2.0 * nb * ngm * ngm / 110.0;
+              cost += qi * kHkNodes * nb * n_of_z(0.5 * zb) + 3.0 * (double)cfg->M * ngm / 22.0 + qi * 2.0 * nb * ngm * ngm / 110.0;
             }
             if (qn + qi > (double)kHkQCap) continue;
             if (cost < best) {
@@ -519,16 +521,29 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         }
       }
       if (boxes) {
-        { EvScope e(cfg, st, SK_K_NEAR); launch_hk_boxes(cfg->dc, db, hin, st); }
+        // the boxes (a chain of small launches) run beside the spread and the FFT, which do not depend on them; the
+        // per-kernel event timing (sk_profile_enable) keeps everything on one stream
+        const bool beside = hin.has_far && !cfg->profile && !g_hk_serial;
+        if (beside) {  // both chains start at once: the spread is issued ahead of the (longer) chain of the boxes
+          HIPCHK(hipEventRecord(cfg->fork_event, st));
+          launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, st);
+          HIPCHK(hipStreamWaitEvent(cfg->side_stream, cfg->fork_event, 0));
+          launch_hk_boxes(cfg->dc, db, hin, cfg->side_stream);
+          HIPCHK(hipEventRecord(cfg->join_event, cfg->side_stream));
+        } else {
+          EvScope e(cfg, st, SK_K_NEAR);
+          launch_hk_boxes(cfg->dc, db, hin, st);
+        }
         if (hin.has_far) {
-          { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, st); }
+          if (!beside) { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, st); }
           {
             EvScope e(cfg, st, SK_K_FFT);
             FFTCHK(rocfft_execution_info_set_stream(cfg->info_hk, st));
             void* in[1] = {db.hk_fft};
             FFTCHK(rocfft_execute(cfg->plan_hk, in, nullptr, cfg->info_hk));
           }
-          { EvScope e(cfg, st, SK_K_INTERP); launch_hk_far(cfg->dc, cfg->d_ec, db, hin, hp.a, t & 1, n, raw, st); }
+          if (beside) HIPCHK(hipStreamWaitEvent(st, cfg->join_event, 0));
+          { EvScope e(cfg, st, SK_K_INTERP); launch_hk_far(cfg->dc, cfg->d_ec, db, hin, t & 1, n, raw, st); }
         }
         if (hin.lag_cnt > 0) {
           EvScope e(cfg, st, SK_K_NEAR);
@@ -800,11 +815,9 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   double* errs = (double*)base; base += a8;
   double* scr = (double*)base; base += nscr * a8;
   long long* d_nu = (long long*)base; base += 256;
-  sort_unique(d_xs, (long long)n, uxs, inv, d_nu, base, tb, st);
-  HIPCHK(hipMemcpyAsync(cfg->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  long long nu = 0;
+  if (sort_unique_sync(d_xs, (long long)n, uxs, inv, d_nu, cfg->h_nuniq, base, tb, st, &nu)) return fail(SK_EHIP, "sort failed");
   cfg->stats.n_syncs++;
-  const long long nu = *cfg->h_nuniq;
   cfg->stats.n_unique = nu;
   rc = run_core(cfg, uxs, nu, k0, ks0, ks, errs, scr, st, false);
   if (rc) return rc;
@@ -841,10 +854,9 @@ int sort_unique_on_device(sk_config* cfg, const double* xs, size_t n, std::vecto
   void* tmp = buf + 3 * a8 + 256;
   rc = h2d_doubles(cfg, d_xs, xs, n, st, nullptr);
   if (rc) return rc;
-  sort_unique(d_xs, (long long)n, d_ux, d_inv, d_nu, tmp, tb, st);
-  HIPCHK(hipMemcpyAsync(cfg->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  const size_t nu = (size_t)*cfg->h_nuniq;
+  long long nu_ll = 0;
+  if (sort_unique_sync(d_xs, (long long)n, d_ux, d_inv, d_nu, cfg->h_nuniq, tmp, tb, st, &nu_ll)) return fail(SK_EHIP, "sort failed");
+  const size_t nu = (size_t)nu_ll;
   uxs.resize(nu);
   inv.resize(n);
   rc = d2h_doubles(cfg, uxs.data(), d_ux, nu, st);
@@ -1169,6 +1181,12 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
       cfg->owned.push_back(p5);
       db.hk_dct = (double*)p5;
     }
+    if (hipStreamCreateWithFlags(&cfg->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&cfg->fork_event, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&cfg->join_event, hipEventDisableTiming) != hipSuccess) {
+      sk_config_destroy(cfg);
+      return fail(SK_EHIP, "hipStreamCreate (Hankel side stream) failed");
+    }
     if (!std::getenv("SK_HK_LEVELS")) {
       // inner box (sk_hankel_inner.inc): partial moments of every source wave; the bands are chosen per step
       cfg->hk_nb = 1;
@@ -1242,6 +1260,9 @@ void sk_config_destroy(sk_config* cfg) {
     if (q) hipHostFree(q);
   if (cfg->own_stream) hipStreamDestroy(cfg->own_stream);
   if (cfg->copy_stream) hipStreamDestroy(cfg->copy_stream);
+  if (cfg->side_stream) hipStreamDestroy(cfg->side_stream);
+  if (cfg->fork_event) hipEventDestroy(cfg->fork_event);
+  if (cfg->join_event) hipEventDestroy(cfg->join_event);
   if (cfg->up_event) hipEventDestroy(cfg->up_event);
   for (hipEvent_t e : cfg->ev_pool) hipEventDestroy(e);
   delete cfg;
@@ -1385,11 +1406,7 @@ int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs
   long long nu = (long long)n;
   const bool sorted = (order == SK_ORDER_SORTED);
   if (!sorted) {
-    sort_unique(d_xs, (long long)n, uxs, inv, d_nu, tmp, tb, st);
-    if (hipMemcpyAsync(c0->h_nuniq, d_nu, sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-      return fail(SK_EHIP, "sort failed");
-    nu = *c0->h_nuniq;
+    if (sort_unique_sync(d_xs, (long long)n, uxs, inv, d_nu, c0->h_nuniq, tmp, tb, st, &nu)) return fail(SK_EHIP, "sort failed");
   }
   for (size_t c = 0; c < ncfg; ++c) {
     const int pd = param_derivative ? param_derivative[c] : 0;

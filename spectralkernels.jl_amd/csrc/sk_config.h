@@ -99,6 +99,8 @@ struct sk_config {
   hipStream_t own_stream = nullptr;
   hipStream_t copy_stream = nullptr;  // bulk upload of the host-array entry, beside the first step (up_event)
   hipEvent_t up_event = nullptr;
+  hipStream_t side_stream = nullptr;  // Hankel path: the boxes run beside the NUFFT (fork / join events)
+  hipEvent_t fork_event = nullptr, join_event = nullptr;
   // last call
   sk_stats stats;
   std::vector<TraceRec> trace;

@@ -55,6 +55,7 @@ struct HkInner {
   double r_c, ell, pa, pb;
   double om0, elln, r_hi;
   long long lag_lo, lag_cnt;   // the inner lags: indices [lag_lo, lag_lo + lag_cnt) of the sorted lag array
+  HkSeries ser;                // Hankel's expansion of J_nu: the series NUFFT and the large-argument kernel values
 };
 
 // Joint march of several integrands on one lag set (sk_kernel_values_joint; src/derivatives.jl:51-112 calls
@@ -302,8 +303,9 @@ void launch_lw_finish(const DevConst& dc, const DevBuffers& db, int slot, long l
 void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, double om, hipStream_t st);
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st);
 void launch_hk_boxes(const DevConst& dc, const DevBuffers& db, const HkInner& hi, hipStream_t st);
-void launch_hk_far(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HkInner& hi, const double* a, int slot,
-                   long long n, int raw, hipStream_t st);
+void hk_series_fill(HkSeries& ser, const double* a, int nu);
+void launch_hk_far(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HkInner& hi, int slot, long long n, int raw,
+                   hipStream_t st);
 void launch_hk_iinterp(const DevConst& dc, const DevBuffers& db, const HkInner& hi, int slot, long long n, int raw, hipStream_t st);
 int hk_inner_waves(const DevConst& dc, int nb);
 void launch_hk_interp(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HankelPlan& hp, int level, int slot,
@@ -361,7 +363,10 @@ void launch_check_sorted(const double* xs, long long n, int* flags, hipStream_t 
 size_t sort_unique_temp_bytes(long long n);
 // returns number of unique values in *n_unique (device int64) and fills uxs, inv
 void sort_unique(const double* xs, long long n, double* uxs, long long* inv, long long* d_n_unique, void* temp,
-                 size_t temp_bytes, hipStream_t st);
+                 size_t temp_bytes, hipStream_t st, bool use_lib);
+// sort_unique + the count on the host (synchronises `st`; h_nu pinned); the library sort when the bucket sort gave up
+int sort_unique_sync(const double* xs, long long n, double* uxs, long long* inv, long long* d_n_unique, long long* h_nu,
+                     void* temp, size_t temp_bytes, hipStream_t st, long long* nu);
 void launch_gather(const double* ks, const double* errs, const long long* inv, long long n, double* vals, double* errs_out,
                    hipStream_t st);
 

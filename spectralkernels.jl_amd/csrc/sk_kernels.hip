@@ -2100,19 +2100,20 @@ void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& 
   hipLaunchKernelGGL(k_hk_cheb, dim3((unsigned)(hp.near_levels * 2)), dim3(kHkNodes), 0, st, db, hp.direct_inner ? hp.L : -1,
                      hp.inner_cnt);
 }
-void launch_hk_far(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HkInner& hi, const double* a, int slot,
-                   long long n, int raw, hipStream_t st) {
-  HkSeries ser;
+void hk_series_fill(HkSeries& ser, const double* a, int nu) {
   for (int k = 0; k < kHkTerms; ++k) ser.a[k] = a[k];
-  const int q8 = (2 * hi.nu + 1) & 7;  // (2 nu + 1) pi / 4: exact octant values
+  const int q8 = (2 * nu + 1) & 7;  // (2 nu + 1) pi / 4: exact octant values
   const double h = 0.70710678118654752440;
   const double c8[8] = {1, h, 0, -h, -1, -h, 0, h}, s8[8] = {0, h, 1, h, 0, -h, -1, -h};
   ser.cs = c8[q8];
   ser.sn = s8[q8];
+}
+void launch_hk_far(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HkInner& hi, int slot, long long n, int raw,
+                   hipStream_t st) {
   // grid: the lags above r_c; the kernel leaves where its block starts beyond the active set
   const long long cnt = n - (hi.lag_lo + hi.lag_cnt);
   if (cnt <= 0) return;
-  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_hk_far<W>, dim3(nblk(cnt, 256)), dim3(256), 0, st, dc, ec, db, hi, ser, slot, n, raw));
+  SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_hk_far<W>, dim3(nblk(cnt, 256)), dim3(256), 0, st, dc, ec, db, hi, slot, n, raw));
 }
 void launch_hk_iinterp(const DevConst& dc, const DevBuffers& db, const HkInner& hi, int slot, long long n, int raw, hipStream_t st) {
   if (hi.lag_cnt > 0)
@@ -2363,12 +2364,30 @@ void launch_check_sorted(const double* xs, long long n, int* flags, hipStream_t 
   hipLaunchKernelGGL(k_check_sorted, dim3(nblk(n, 256)), dim3(256), 0, st, xs, n, flags);
 }
 
-__global__ void k_make_keys(const double* xs, long long n, unsigned long long* keys, long long* idx) {
+// keys (the bit pattern of a non-negative double orders like the double), identity permutation and -- for the bucket
+// sort -- the largest key of every workgroup (maxkey may be null)
+__global__ void __launch_bounds__(256) k_make_keys(const double* xs, long long n, unsigned long long* keys, long long* idx,
+                                                   unsigned long long* maxkey) {
+  __shared__ unsigned long long sm[4];
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double x = xs[i];
-  keys[i] = (x == 0.0) ? 0ull : (unsigned long long)__double_as_longlong(x);  // -0.0 == 0.0
-  idx[i] = i;
+  unsigned long long k = 0ull;
+  if (i < n) {
+    double x = xs[i];
+    k = (x == 0.0) ? 0ull : (unsigned long long)__double_as_longlong(x);  // -0.0 == 0.0
+    keys[i] = k;
+    idx[i] = i;
+  }
+  if (!maxkey) return;
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(k, off, 64);
+    k = o > k ? o : k;
+  }
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = k;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < 4; ++q) k = sm[q] > k ? sm[q] : k;
+    maxkey[blockIdx.x] = k;  // per workgroup: k_bk_range takes their maximum (one atomicMax address for 3907 workgroups: 48 us)
+  }
 }
 __global__ void k_heads(const unsigned long long* keys, long long n, long long* head) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2376,8 +2395,12 @@ __global__ void k_heads(const unsigned long long* keys, long long n, long long* 
   head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 __global__ void k_scatter_unique(const unsigned long long* keys, const long long* perm, const long long* uid1,
-                                 long long n, double* uxs, long long* inv, long long* n_unique) {
+                                 long long n, double* uxs, long long* inv, long long* n_unique, const int* overflow) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (overflow && *overflow) {  // the bucket sort gave up (sort_unique): nothing below is sorted -- tell the host
+    if (i == 0) *n_unique = -1;
+    return;
+  }
   if (i >= n) return;
   const long long u = uid1[i] - 1;
   if (i == 0 || uid1[i] != uid1[i - 1]) uxs[u] = __longlong_as_double((long long)keys[i]);
@@ -2395,6 +2418,241 @@ __global__ void k_gather(const double* ks, const double* errs, const long long* 
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ---- bucket sort of (key, index) pairs for keys that spread over their range (pairwise distances, random lags):
+// kBkN equal-width buckets of the value range, one pass to count, one to scatter, one workgroup per bucket to sort it in
+// LDS (bitonic, by key then index: the result is the stable sort, independent of the scatter order).  84 us -> see
+// DESIGN 3f; rocprim's radix_sort_pairs runs a merge sort at this size (block sort + 20 merge launches, 195 us for 1e6
+// pairs).  A bucket beyond kBkCap (few distinct values, clustered lags) raises `overflow`: the host then sorts with
+// rocprim instead.
+constexpr int kBkN = 8192;
+constexpr int kBkCap = 2048;
+struct BkState { unsigned long long maxkey; int overflow; int pad; };
+
+__device__ __forceinline__ int bk_bucket(unsigned long long key, double scale) {
+  const double x = __longlong_as_double((long long)key);
+  const double b = x * scale;
+  return (b >= 0.0 && b < (double)kBkN) ? (int)b : kBkN - 1;  // the top of the range, NaN and negative keys: last bucket
+}
+__global__ void __launch_bounds__(1024) k_bk_range(const unsigned long long* wgmax, int nw, BkState* stt) {
+  __shared__ unsigned long long sm[16];
+  unsigned long long m = 0ull;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) m = wgmax[i] > m ? wgmax[i] : m;
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(m, off, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < 16; ++q) m = sm[q] > m ? sm[q] : m;
+    stt->maxkey = m;
+    stt->overflow = 0;
+  }
+}
+__device__ __forceinline__ double bk_scale(const BkState* stt) {
+  const double mx = __longlong_as_double((long long)stt->maxkey);
+  return (mx > 0.0 && mx < 1.0e300) ? (double)kBkN / mx : 0.0;  // degenerate range: everything in the last bucket
+}
+// Counting sort by bucket without contended atomics: kBkWgs workgroups each own a fixed (grid-stride) share of the keys.
+// k_bk_hist: the share's histogram (LDS atomics) -> table[wg][bucket]; k_bk_colscan: per bucket the exclusive prefix over
+// the workgroups (in place) and the bucket's count; k_bk_scan: bucket starts; k_bk_scatter: slot = start of the bucket +
+// prefix of the workgroup + rank inside the workgroup's share (LDS atomics again: the order inside a bucket is arbitrary,
+// the bucket is sorted by (key, index) afterwards).
+constexpr int kBkWgs = 256;
+__global__ void __launch_bounds__(1024) k_bk_hist(const unsigned long long* keys, long long n, const BkState* stt, int* table) {
+  __shared__ int h[kBkN];
+  for (int t = threadIdx.x; t < kBkN; t += blockDim.x) h[t] = 0;
+  __syncthreads();
+  const double scale = bk_scale(stt);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    atomicAdd(&h[bk_bucket(keys[i], scale)], 1);
+  __syncthreads();
+  for (int t = threadIdx.x; t < kBkN; t += blockDim.x) table[(size_t)blockIdx.x * kBkN + t] = h[t];
+}
+__global__ void __launch_bounds__(64) k_bk_colscan(int* table, int nwg, int* counts) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= kBkN) return;
+  int run = 0;
+  for (int w0 = 0; w0 < nwg; w0 += 16) {  // 16 independent loads in flight, then their prefixes
+    int c[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c[q] = (w0 + q < nwg) ? table[(size_t)(w0 + q) * kBkN + b] : 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if (w0 + q < nwg) table[(size_t)(w0 + q) * kBkN + b] = run;
+      run += c[q];
+    }
+  }
+  counts[b] = run;
+}
+// starts[b] = first slot of bucket b (exclusive scan); overflow if a bucket exceeds kBkCap
+__global__ void __launch_bounds__(1024) k_bk_scan(const int* counts, int* starts, BkState* stt) {
+  __shared__ int part[1024];
+  constexpr int PER = kBkN / 1024;
+  int loc[PER], sum = 0, mx = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    loc[q] = counts[threadIdx.x * PER + q];
+    sum += loc[q];
+    mx = loc[q] > mx ? loc[q] : mx;
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - sum;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    starts[threadIdx.x * PER + q] = run;
+    run += loc[q];
+  }
+  if (threadIdx.x == 1023) starts[kBkN] = run;
+  if (mx > kBkCap) atomicOr(&stt->overflow, 1);
+}
+__global__ void __launch_bounds__(1024) k_bk_scatter(const unsigned long long* keys, long long n, const BkState* stt,
+                                                     const int* table, const int* starts, ulonglong2* rec) {
+  __shared__ int h[kBkN];
+  if (stt->overflow) return;
+  for (int t = threadIdx.x; t < kBkN; t += blockDim.x) h[t] = starts[t] + table[(size_t)blockIdx.x * kBkN + t];
+  __syncthreads();
+  const double scale = bk_scale(stt);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long k = keys[i];
+    const int pos = atomicAdd(&h[bk_bucket(k, scale)], 1);
+    rec[pos] = make_ulonglong2(k, (unsigned long long)i);  // one 16-byte store per pair (two 8-byte ones: twice the partial lines)
+  }
+}
+// Sorting the buckets by key (equal keys may come out in any order: they are merged into one unique lag next): bitonic
+// networks, padded to a power of two.
+// k_bk_sort_wave: one WAVE per bucket of at most 512 pairs (nearly all: 122 on average at 1e6 pairs), E = 1, 2, 4 or 8
+// pairs per lane in registers: exchanges at distance >= 64 are register to register, the others lane shuffles -- no LDS, no
+// barriers (a workgroup per bucket with an LDS network spends its time in barriers and launch latency: 43-50 us; rocprim's
+// segmented sort 96 us plus a host round trip).
+template <int E>
+__device__ __forceinline__ void bk_sort_regs(const ulonglong2* rec, int lo, int cnt, unsigned long long* keys_out,
+                                             long long* idx_out) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long k[E];
+  long long ix[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int t = e * 64 + lane;
+    ulonglong2 r = make_ulonglong2(~0ull, 0x7fffffffffffffffull);
+    if (t < cnt) r = rec[lo + t];
+    k[e] = r.x;
+    ix[e] = (long long)r.y;
+  }
+  // stage loops are NOT unrolled (unrolled, the four instantiations are 90 KB of code and the kernel waits for its
+  // instructions: 47 us); register-to-register exchanges need static indices, hence one body per distance 64, 128, 256
+  auto xchg = [&](auto D, int kk) {
+    constexpr int d = decltype(D)::value;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int f = e ^ d;
+      if (f > e && f < E) {
+        const bool up = (((e * 64) & kk) == 0);  // lane bits are below 64 <= j < kk: the direction depends on e only
+        const bool sw = up ? (k[e] > k[f]) : (k[e] < k[f]);
+        if (sw) {
+          const unsigned long long tk = k[e]; k[e] = k[f]; k[f] = tk;
+          const long long ti = ix[e]; ix[e] = ix[f]; ix[f] = ti;
+        }
+      }
+    }
+  };
+#pragma unroll 1
+  for (int kk = 2; kk <= 64 * E; kk <<= 1) {
+#pragma unroll 1
+    for (int j = kk >> 1; j >= 64; j >>= 1) {
+      if (j == 64) xchg(std::integral_constant<int, 1>(), kk);
+      else if (j == 128) xchg(std::integral_constant<int, 2>(), kk);
+      else xchg(std::integral_constant<int, 4>(), kk);
+    }
+#pragma unroll 1
+    for (int j = (kk >> 1) < 32 ? (kk >> 1) : 32; j > 0; j >>= 1) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const unsigned long long ok = __shfl_xor(k[e], j, 64);
+        const long long oi = __shfl_xor(ix[e], j, 64);
+        const int t = e * 64 + lane;
+        const bool keep_min = ((t & j) == 0) == ((t & kk) == 0);
+        if (keep_min ? (ok < k[e]) : (ok > k[e])) {
+          k[e] = ok;
+          ix[e] = oi;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int t = e * 64 + lane;
+    if (t < cnt) {
+      keys_out[lo + t] = k[e];
+      idx_out[lo + t] = ix[e];
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_bk_sort_wave(const ulonglong2* rec, const int* starts, const BkState* stt,
+                                                      unsigned long long* keys_out, long long* idx_out) {
+  const int bkt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lo = starts[bkt], cnt = starts[bkt + 1] - lo;
+  if (stt->overflow || cnt <= 0 || cnt > 512) return;  // wave-uniform
+  if (cnt <= 64) bk_sort_regs<1>(rec, lo, cnt, keys_out, idx_out);
+  else if (cnt <= 128) bk_sort_regs<2>(rec, lo, cnt, keys_out, idx_out);
+  else if (cnt <= 256) bk_sort_regs<4>(rec, lo, cnt, keys_out, idx_out);
+  else bk_sort_regs<8>(rec, lo, cnt, keys_out, idx_out);
+}
+// k_bk_sort_big: the buckets of 513 .. kBkCap pairs, 64 buckets per workgroup (few or none qualify), network in LDS
+__global__ void __launch_bounds__(256) k_bk_sort_big(const ulonglong2* rec, const int* starts, const BkState* stt,
+                                                     unsigned long long* keys_out, long long* idx_out) {
+  __shared__ unsigned long long sk_[kBkCap];
+  __shared__ long long si_[kBkCap];
+  if (stt->overflow) return;
+  for (int bq = 0; bq < 64; ++bq) {
+    const int bkt = blockIdx.x * 64 + bq;
+    const int lo = starts[bkt], cnt = starts[bkt + 1] - lo;
+    if (cnt <= 512 || cnt > kBkCap) continue;  // workgroup-uniform
+    int P = 1024;
+    while (P < cnt) P <<= 1;
+    for (int t = threadIdx.x; t < P; t += 256) {
+      ulonglong2 r = make_ulonglong2(~0ull, 0x7fffffffffffffffull);
+      if (t < cnt) r = rec[lo + t];
+      sk_[t] = r.x;
+      si_[t] = (long long)r.y;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = threadIdx.x; t < P / 2; t += 256) {
+          const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // comparator t of this stage: (a, a + j)
+          const int b = a + j;
+          const bool up = (a & k) == 0;
+          const unsigned long long ka = sk_[a], kb = sk_[b];
+          const long long ia = si_[a], ib = si_[b];
+          const bool gt = ka > kb || (ka == kb && ia > ib);
+          if (gt == up) {
+            sk_[a] = kb; sk_[b] = ka;
+            si_[a] = ib; si_[b] = ia;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int t = threadIdx.x; t < cnt; t += 256) {
+      keys_out[lo + t] = sk_[t];
+      idx_out[lo + t] = si_[t];
+    }
+    __syncthreads();
+  }
+}
+
+// the region behind the bucket starts: per-workgroup maxima, then the histogram table
+static size_t bk_table_bytes(long long n, size_t seg_b) {
+  return align_up(std::max(std::max((size_t)kBkWgs * kBkN * sizeof(int), (size_t)(n / 256 + 1) * sizeof(unsigned long long)), seg_b));
+}
 size_t sort_unique_temp_bytes(long long n) {
   size_t sort_b = 0, scan_b = 0;
   unsigned long long* k = nullptr;
@@ -2402,11 +2660,15 @@ size_t sort_unique_temp_bytes(long long n) {
   (void)rocprim::radix_sort_pairs(nullptr, sort_b, k, k, v, v, (size_t)n, 0, 64, 0);
   (void)rocprim::inclusive_scan(nullptr, scan_b, v, v, (size_t)n, rocprim::plus<long long>(), 0);
   size_t lib = sort_b > scan_b ? sort_b : scan_b;
+  const size_t seg_b = 0;
+  const size_t bk = align_up(sizeof(BkState)) + 2 * align_up((size_t)(kBkN + 1) * sizeof(int)) + bk_table_bytes(n, seg_b);
+  lib = lib > bk ? lib : bk;
   return align_up(lib) + 6 * align_up((size_t)n * 8) + 256;
 }
 
+// use_lib = false: bucket sort first; *d_n_unique = -1 if it overflowed (call again with use_lib = true)
 void sort_unique(const double* xs, long long n, double* uxs, long long* inv, long long* d_n_unique, void* temp,
-                 size_t temp_bytes, hipStream_t st) {
+                 size_t temp_bytes, hipStream_t st, bool use_lib) {
   char* base = (char*)temp;
   const size_t arr = align_up((size_t)n * 8);
   unsigned long long* keys_in = (unsigned long long*)base; base += arr;
@@ -2417,14 +2679,55 @@ void sort_unique(const double* xs, long long n, double* uxs, long long* inv, lon
   long long* uid1 = (long long*)base; base += arr;
   void* lib = base;
   size_t lib_bytes = temp_bytes - 6 * arr;
-  hipLaunchKernelGGL(k_make_keys, dim3(nblk(n, 256)), dim3(256), 0, st, xs, n, keys_in, idx_in);
   size_t sb = lib_bytes;
-  (void)rocprim::radix_sort_pairs(lib, sb, keys_in, keys_out, idx_in, idx_out, (size_t)n, 0, 64, st);
+  const int* overflow = nullptr;
+  if (use_lib || n < 32768 || n >= 0x7fffffffll) {
+    hipLaunchKernelGGL(k_make_keys, dim3(nblk(n, 256)), dim3(256), 0, st, xs, n, keys_in, idx_in, (unsigned long long*)nullptr);
+    (void)rocprim::radix_sort_pairs(lib, sb, keys_in, keys_out, idx_in, idx_out, (size_t)n, 0, 64, st);
+  } else {
+    // `head` and `uid1` (adjacent) hold the scattered pairs until the buckets are sorted; the library region the small arrays
+    BkState* stt = (BkState*)lib;
+    int* counts = (int*)((char*)lib + align_up(sizeof(BkState)));
+    int* starts = (int*)((char*)counts + align_up((size_t)(kBkN + 1) * sizeof(int)));
+    int* table = (int*)((char*)starts + align_up((size_t)(kBkN + 1) * sizeof(int)));
+    unsigned long long* wgmax = (unsigned long long*)table;  // read by k_bk_range before k_bk_hist overwrites the table
+    hipLaunchKernelGGL(k_make_keys, dim3(nblk(n, 256)), dim3(256), 0, st, xs, n, keys_in, idx_in, wgmax);
+    hipLaunchKernelGGL(k_bk_range, dim3(1), dim3(1024), 0, st, wgmax, (int)nblk(n, 256), stt);
+    const int nwg = (int)(nblk(n, 1024) < (unsigned)kBkWgs ? nblk(n, 1024) : (unsigned)kBkWgs);
+    hipLaunchKernelGGL(k_bk_hist, dim3(nwg), dim3(1024), 0, st, keys_in, n, stt, table);
+    hipLaunchKernelGGL(k_bk_colscan, dim3(kBkN / 64), dim3(64), 0, st, table, nwg, counts);
+    hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, st, counts, starts, stt);
+    ulonglong2* rec = (ulonglong2*)head;  // head and uid1 are adjacent: n 16-byte records
+    hipLaunchKernelGGL(k_bk_scatter, dim3(nwg), dim3(1024), 0, st, keys_in, n, stt, table, starts, rec);
+    hipLaunchKernelGGL(k_bk_sort_wave, dim3(kBkN / 4), dim3(256), 0, st, rec, starts, stt, keys_out, idx_out);
+    hipLaunchKernelGGL(k_bk_sort_big, dim3(kBkN / 64), dim3(256), 0, st, rec, starts, stt, keys_out, idx_out);
+    // the flag outlives the scan below (which reuses the library region): keep a copy beside the result
+    overflow = &stt->overflow;
+  }
+  if (overflow) {
+    // heads / scan / scatter on unsorted data are harmless except for the scatter's indexed write, which checks the flag
+    // -- but the scan's temporary storage overlays BkState: move the flag into d_n_unique's neighbour first
+    (void)hipMemcpyAsync((char*)d_n_unique + 8, overflow, sizeof(int), hipMemcpyDeviceToDevice, st);
+    overflow = (const int*)((char*)d_n_unique + 8);
+  }
   hipLaunchKernelGGL(k_heads, dim3(nblk(n, 256)), dim3(256), 0, st, keys_out, n, head);
   sb = lib_bytes;
   (void)rocprim::inclusive_scan(lib, sb, head, uid1, (size_t)n, rocprim::plus<long long>(), st);
   hipLaunchKernelGGL(k_scatter_unique, dim3(nblk(n, 256)), dim3(256), 0, st, keys_out, idx_out, uid1, n, uxs, inv,
-                     d_n_unique);
+                     d_n_unique, overflow);
+}
+
+int sort_unique_sync(const double* xs, long long n, double* uxs, long long* inv, long long* d_n_unique, long long* h_nu,
+                     void* temp, size_t temp_bytes, hipStream_t st, long long* nu) {
+  for (int pass = 0; pass < 2; ++pass) {
+    sort_unique(xs, n, uxs, inv, d_n_unique, temp, temp_bytes, st, pass == 1);
+    if (hipMemcpyAsync(h_nu, d_n_unique, sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return 1;
+    if (*h_nu >= 0) break;
+  }
+  *nu = *h_nu;
+  return *h_nu < 0 ? 1 : 0;
 }
 
 void launch_gather(const double* ks, const double* errs, const long long* inv, long long n, double* vals, double* eo,

@@ -1,0 +1,49 @@
+"""Unsorted lag arrays (src/adaptive.jl:99-120: unique + sort, evaluate, gather back): the device bucket sort (csrc/
+sk_kernels.hip, k_bk_*) and its fall-back to the library sort must give, bit for bit, what the march gives on the sorted
+unique lags."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def check(sk, rs, **kw):
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1.0, 1.0, 1.5), quadspec=(64, 4), tol=1e-7, **kw)
+    k0 = sk.compute_k0(cfg)
+    ux, inv = np.unique(np.where(rs == 0.0, 0.0, rs), return_inverse=True)
+    ks_u, es_u = sk.kernel_values(cfg, ux, k0=k0)
+    ks, es = sk.kernel_values(cfg, rs, k0=k0)
+    assert cfg.last_stats()["n_unique"] == ux.size
+    assert np.array_equal(ks, ks_u[inv]) and np.array_equal(es, es_u[inv], equal_nan=True)
+    # device-resident entry too
+    n = rs.size
+    d_rs, d_ks, d_es = sk.DeviceArray.from_host(rs), sk.DeviceArray(n), sk.DeviceArray(n)
+    sk.kernel_values_device(cfg, d_rs.ptr, n, k0, d_ks.ptr, d_es.ptr)
+    sk.synchronize()
+    assert np.array_equal(d_ks.to_host(), ks)
+
+
+@pytest.mark.parametrize("name,make", [
+    ("uniform, 10 % duplicates", lambda g: np.r_[g.uniform(0, 2, 180000), g.uniform(0, 2, 20000).repeat(2)[:20000]]),
+    ("pairwise distances", lambda g: np.sqrt(((g.uniform(0, 1, (500, 1, 2)) - g.uniform(0, 1, (1, 400, 2))) ** 2).sum(-1)).ravel()),
+    ("50 distinct values (buckets overflow: library sort)", lambda g: g.choice(g.uniform(0, 1, 50), 100000)),
+    ("all equal", lambda g: np.full(70000, 0.37)),
+    ("exponential: mass at the bottom of the range", lambda g: g.exponential(0.01, 150000)),
+    ("zeros of both signs and one huge lag", lambda g: np.r_[g.uniform(0, 1, 60000), [0.0, -0.0, 0.0, 50.0]]),
+    ("below the bucket-sort size", lambda g: g.uniform(0, 1, 5000).repeat(2)),
+])
+def test_unsorted_lags_match_sorted_unique_bit_for_bit(sk, name, make):
+    g = np.random.default_rng(12)
+    rs = make(g)
+    g.shuffle(rs)
+    check(sk, rs)
+
+
+def test_unsorted_invalid_lags_are_rejected(sk):
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1.0, 1.0, 1.5), quadspec=(64, 4))
+    rs = np.random.default_rng(1).uniform(0, 1, 50000)
+    for bad in (-0.25, float("nan")):
+        x = rs.copy()
+        x[1234] = bad
+        with pytest.raises(sk.SpectralKernelsError):
+            sk.kernel_values(cfg, x, k0=1.0)
