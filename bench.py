@@ -41,7 +41,7 @@ WORKLOADS = {
                sdf=("matern", (1.0, 1.0, 1.5)), kw=dict(tol=1e-8), n=10 ** 6, lo=-6.0, hi=0.0),
     "C4": dict(desc="dim=2 isotropic S=0.7(1.3^2+w^2)^-2.8 (scripts/simple_2d.jl), 1e6 pairwise lags |x_i-y_j| of 1e3 x 1e3 "
                     "splitmix64-seeded uniform points in [0,1]^2, tol=1e-8, quadspec=(4096,16); fast Hankel transform "
-                    "(asymptotic-series NUFFTs + near-field Chebyshev interpolants)",
+                    "(one asymptotic-series NUFFT per panel + Chebyshev-compressed near / inner boxes)",
                sdf=("matern", (0.7, 1.3, 1.8, 2.0)), kw=dict(tol=1e-8, dim=2), n=10 ** 6, lo=None, hi=None),
     "C5": dict(desc="Matern (2.14,0.97,0.89), 1e5 uniform r in [0,5.1], tol=1e-12, quadspec=(256,16)",
                sdf=("matern", (2.14, 0.97, 0.89)), kw=dict(tol=1e-12, quadspec=(256, 16)), n=10 ** 5, lo=None, hi=5.1),
@@ -294,7 +294,7 @@ def main():
     else:  # dim >= 2 (fast Hankel transform): whatever the events say takes longest -- spread, FFT, interpolation or near field
         dom = max((k for k in acc if k != "advance"), key=lambda k: acc[k]["total_ms"])
     hk_names = {"gen": "k_gen", "spread": "k_spread_multi", "fft": "rocfft (batch 2 x series terms, length n2)",
-                "interp": "k_hk_interp", "near": "k_hk_near + k_hk_cheb"}
+                "interp": "k_hk_far", "near": "boxes: k_hk_moments / k_hk_msum / k_hk_eqw / k_hk_nodes / k_hk_icheb / k_hk_iinterp"}
     dom_name = ("k_interp_b" if dom == "interp" else "k_" + dom) if batched else hk_names.get(dom, "k_" + dom)
     M = cfg.quadspec[0] * cfg.quadspec[1]
     n1 = M  # spread grid of this geometry; the batched FFT plan transforms 4 K grids of n1
@@ -311,10 +311,10 @@ def main():
         avg_ms = v["total_ms"] / v["launches"]
         items = v["active_items"] / v["launches"]
         if not batched:
-            # fast Hankel transform, per launch: the series terms of one lag level through the fixed spread geometry
+            # fast Hankel transform, per launch: the series terms of the panel through the fixed spread geometry
             NT = {8: 6, 10: 8, 12: 10, 14: 13, 16: 16}.get(cfg.nufft_width, 10)  # hk_terms(w), sk_device.h
             n2 = 2 * n1
-            if k == "interp":    # one level's lags: r, the running sums in and out (the level's share of sum_active)
+            if k == "interp":    # the lags above r_c: r, the running sums in and out (their share of sum_active)
                 b = 40.0 * 10 * st["sum_active"] / v["launches"]
             elif k == "spread":  # 3M (strength, node) pairs + positions in; NT terms x 2 rules x n2 complex out
                 b = 24.0 * 3 * M + NT * 2 * n2 * 16.0
@@ -322,7 +322,7 @@ def main():
                 b = 2 * NT * 2 * n2 * 16.0
             elif k == "gen":
                 b = 48.0 * M + 48.0 * M
-            else:                # near field: O(nodes x sources) Bessel evaluations from an L2-resident source list
+            else:                # boxes: Bessel evaluations between equivalent sources and Chebyshev nodes, L2-resident
                 b = 0.0
         elif k == "interp":
             b = interp_bytes_total / v["launches"]
@@ -362,8 +362,9 @@ def main():
                 # its state loads (DESIGN.md "Launch floor")
                 "launch_floor_us": floor}
     if not batched:
-        roofline["note"] = ("dim >= 2: per level of lags one k_spread_multi / rocFFT (batch 2 x series terms) / k_hk_interp "
-                            "triple plus the near-field sums; `kernel` is the launch kind with the largest event time")
+        roofline["note"] = ("dim >= 2: per panel one k_spread_multi / rocFFT (batch 2 x series terms) / k_hk_far triple for the lags "
+                            "above r_c plus the two compressed boxes (event-timed on one stream here; the march runs them beside "
+                            "the spread and the FFT); `kernel` is the launch kind with the largest event time")
         roofline["per_kernel_share"] = {k: round(acc[k]["total_ms"] / max(1e-12, sum(a["total_ms"] for a in acc.values())), 3)
                                         for k in acc if acc[k]["launches"]}
     if "spread" in roofline["per_kernel"] and batched:

@@ -278,10 +278,12 @@ static int run_fft(sk_config* cfg, hipStream_t st) {
 }
 
 static int run_fft_b(sk_config* cfg, hipStream_t st) {
-  FFTCHK(rocfft_execution_info_set_stream(cfg->info_b, st));
+  const bool one = cfg->dc.K == 1 && cfg->plan_b1;
+  rocfft_execution_info info = one ? cfg->info_b1 : cfg->info_b;
+  FFTCHK(rocfft_execution_info_set_stream(info, st));
   void* in[1] = {cfg->db.bfft};
   void* out[1] = {cfg->db.bfft_out};
-  FFTCHK(rocfft_execute(cfg->plan_b, in, out, cfg->info_b));
+  FFTCHK(rocfft_execute(one ? cfg->plan_b1 : cfg->plan_b, in, out, info));
   return SK_OK;
 }
 
@@ -352,6 +354,15 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   int mode = SK_MODE_INIT;
   // device-resident dim-1 march on a catalogue SDF: batched steps (sk_batch_kernels.inc)
   const bool batched = !host_step && cfg->dc.dim == 1 && !g_no_fuse;
+  if (batched && cfg->k_adaptive) {
+    if (cfg->narrow && n == cfg->probe_n && cfg->narrow_calls < 63) {
+      cfg->dc.K = 1;
+      cfg->narrow_calls++;
+    } else {
+      cfg->dc.K = cfg->k_full;
+      cfg->narrow_calls = 0;
+    }
+  }
   int R = (host_step || batched) ? 1 : 2;
   const int nu_main = cfg->dc.derivative ? cfg->dc.dim / 2 : cfg->dc.dim / 2 - 1;  // src/quadrature.jl:176-180
 
@@ -722,6 +733,10 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   stt.sum_active_steps = batched ? hs->sum_active_steps : hs->sum_active;
   stt.n_fix = batched ? hs->n_fix : 0;
   if (batched) cfg->last_n_steps = hs->n_steps + hs->n_rerun;
+  if (batched && cfg->k_adaptive && cfg->dc.K == cfg->k_full) {
+    cfg->narrow = hs->n_panels >= 2 && hs->n_steps >= hs->n_panels;
+    cfg->probe_n = n;
+  }
   cfg->trace_len = (size_t)hs->trace_len;
   cfg->trace_valid = false;
   if (cfg->profile) {
@@ -1104,6 +1119,25 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
       rocfft_execution_info_set_work_buffer(cfg->info_b, cfg->fft_work_b, wbb);
     }
   }
+  cfg->k_full = dc.K;
+  if (args->batch_panels == 0 && dc.K > 1 && !std::getenv("SK_K_FIXED")) {
+    if (rocfft_plan_create(&cfg->plan_b1, rocfft_placement_notinplace, rocfft_transform_type_complex_inverse,
+                           rocfft_precision_double, 1, len, (size_t)4, nullptr) != rocfft_status_success) {
+      sk_config_destroy(cfg);
+      return fail(SK_EHIP, "rocfft_plan_create (one-panel march) failed");
+    }
+    size_t wb1 = 0;
+    rocfft_plan_get_work_buffer_size(cfg->plan_b1, &wb1);
+    rocfft_execution_info_create(&cfg->info_b1);
+    if (wb1) {
+      if (hipMalloc(&cfg->fft_work_b1, wb1) != hipSuccess) {
+        sk_config_destroy(cfg);
+        return fail(SK_EHIP, "hipMalloc(fft work) failed");
+      }
+      rocfft_execution_info_set_work_buffer(cfg->info_b1, cfg->fft_work_b1, wb1);
+    }
+    cfg->k_adaptive = true;
+  }
   {
     // the finufft1d3-level seam (sk_panel_sums) keeps one plain length-n2 transform, in place
     size_t lens[1] = {(size_t)dc.n2};
@@ -1224,6 +1258,9 @@ void sk_config_destroy(sk_config* cfg) {
   if (!cfg) return;
   hipSetDevice(cfg->device);
   if (cfg->plan) rocfft_plan_destroy(cfg->plan);
+  if (cfg->plan_b1) rocfft_plan_destroy(cfg->plan_b1);
+  if (cfg->info_b1) rocfft_execution_info_destroy(cfg->info_b1);
+  if (cfg->fft_work_b1) hipFree(cfg->fft_work_b1);
   if (cfg->plan_b) rocfft_plan_destroy(cfg->plan_b);
   if (cfg->info_b) rocfft_execution_info_destroy(cfg->info_b);
   if (cfg->fft_work_b) hipFree(cfg->fft_work_b);

@@ -43,6 +43,17 @@ struct sk_config {
   rocfft_plan plan_b = nullptr;     // batched march: 4 K transforms of length n1 (bfft -> bfft_out)
   rocfft_execution_info info_b = nullptr;
   void* fft_work_b = nullptr;
+  // automatic batch_panels only: a config whose marches gain nothing from batching (every step one panel: each panel
+  // retires lags or is bisected) runs the K = 1 instantiations -- lighter kernels -- and re-probes with the full K every
+  // 64th call or when the number of lags changes
+  int k_full = 0;                   // dc.K of the full batch
+  bool k_adaptive = false;
+  bool narrow = false;              // the last full-K march saved no step
+  int narrow_calls = 0;
+  long long probe_n = -1;
+  rocfft_plan plan_b1 = nullptr;    // 4 transforms of length n1 (K = 1)
+  rocfft_execution_info info_b1 = nullptr;
+  void* fft_work_b1 = nullptr;
   rocfft_plan plan_seam = nullptr;  // sk_panel_sums
   rocfft_execution_info info_seam = nullptr;
   void* fft_work_seam = nullptr;
