@@ -101,3 +101,15 @@ def test_boxes_are_deterministic_and_handle_callbacks(sk, monkeypatch):
     c = sk.kernel_values(cb, rs, k0=k0)
     assert np.abs(c[0] - a[0]).max() / abs(k0) <= 5e-13
     assert cb.last_stats()["n_panels"] == cat.last_stats()["n_panels"]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configs_boxes_vs_direct_sums(sk, seed):
+    # tools/diag/hankel_stress.py: random rule, tolerance, dimension (2, 4, 6), order, singularity, SDF and lag distribution
+    # (log-spaced / uniform / clustered): same panel count as the direct Bessel sums, values to 1e-3 of the tolerance
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "diag"))
+    from hankel_stress import run_seed
+    desc, ok, detail = run_seed(sk, seed)
+    assert ok, desc + ": " + detail
