@@ -9,7 +9,7 @@ for WL in C2 C3 C4 C5; do
   cp $O/summary.txt $R/profiles/${RND}_${wl}_summary.txt
   cp $O/summary.json $R/profiles/${RND}_${wl}_summary.json
   grep '^{' $O/bench.json | tail -1 > $R/profiles/${RND}_${wl}_bench.json
-  f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/profiles/${RND}_${wl}_kernel_stats.csv
+  f=$(ls -t $(find $O/stats -name "*kernel_stats.csv") 2>/dev/null | head -1); [ -n "$f" ] && cp $f $R/profiles/${RND}_${wl}_kernel_stats.csv
 done
 # instruction mix of the interpolation kernel (C2 passes), keyed by NUFFT width as bench.py reads it
 python3 - $R $RND <<'PY'
