@@ -796,7 +796,11 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   if (order == SK_ORDER_INVALID) return fail(SK_EINVAL, "lags must be non-negative and finite");
   cfg->stats.n_unique = (int64_t)n;
   int unsorted = 1, invalid = 0;
-  if (order != SK_ORDER_UNSORTED) {
+  // lags of unknown order whose predecessor (same count, same config) was unsorted: sort at once -- the check, the
+  // speculative first step and the round trip for its flags are 50 us of nothing then; the sort reports what the check
+  // would have (invalid lags; an input that was sorted after all, which ends the expectation)
+  const bool sort_first = order == SK_ORDER_UNKNOWN && cfg->expect_unsorted && cfg->expect_n == (long long)n && !lags_ready;
+  if (order != SK_ORDER_UNSORTED && !sort_first) {
     rc = run_core(cfg, d_xs, (long long)n, k0, ks0, d_vals, d_errs, (double*)cfg->ws, st, order == SK_ORDER_UNKNOWN,
                   lags_ready);
     lags_ready = nullptr;  // waited for in the stream
@@ -804,12 +808,16 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
     unsorted = cfg->h_status->flags[0];
     invalid = cfg->h_status->flags[1] & 1;
   }
-  if (order == SK_ORDER_UNKNOWN && (cfg->h_status->flags[1] & 2)) {
+  if (order == SK_ORDER_UNKNOWN && !sort_first) {
+    cfg->expect_unsorted = unsorted && !invalid;
+    cfg->expect_n = (long long)n;
+  }
+  if (order == SK_ORDER_UNKNOWN && !sort_first && (cfg->h_status->flags[1] & 2)) {
     (void)hipStreamSynchronize(st);
     (void)hipMemsetAsync(cfg->db.flags, 0, 2 * sizeof(int), st);
     return fail(SK_EHIP, "internal error: inconsistent device state detected by a kernel guard");
   }
-  if (order == SK_ORDER_UNKNOWN && (unsorted || invalid)) {
+  if (order == SK_ORDER_UNKNOWN && !sort_first && (unsorted || invalid)) {
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMemsetAsync(cfg->db.flags, 0, 2 * sizeof(int), st));
     cfg->ev_recs.clear();
@@ -831,8 +839,17 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   double* scr = (double*)base; base += nscr * a8;
   long long* d_nu = (long long*)base; base += 256;
   long long nu = 0;
-  if (sort_unique_sync(d_xs, (long long)n, uxs, inv, d_nu, cfg->h_nuniq, base, tb, st, &nu)) return fail(SK_EHIP, "sort failed");
+  int was_unsorted = 1, bad_lags = 0;
+  if (sort_unique_sync(d_xs, (long long)n, uxs, inv, d_nu, cfg->h_nuniq, base, tb, st, &nu, &was_unsorted, &bad_lags))
+    return fail(SK_EHIP, "sort failed");
   cfg->stats.n_syncs++;
+  if (sort_first) {
+    if (bad_lags) {
+      cfg->expect_unsorted = false;
+      return fail(SK_EINVAL, "lags must be non-negative and finite");
+    }
+    if (!was_unsorted) cfg->expect_unsorted = false;  // sorted after all: ask first next time
+  }
   cfg->stats.n_unique = nu;
   rc = run_core(cfg, uxs, nu, k0, ks0, ks, errs, scr, st, false);
   if (rc) return rc;
@@ -1080,7 +1097,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
 #undef DA
   if (hipHostMalloc((void**)&cfg->h_status, sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&db.host_status, cfg->h_status, 0) != hipSuccess ||
-      hipHostMalloc((void**)&cfg->h_nuniq, sizeof(long long)) != hipSuccess ||
+      hipHostMalloc((void**)&cfg->h_nuniq, 4 * sizeof(long long)) != hipSuccess ||
       hipHostMalloc((void**)&cfg->h_scal, 32 * sizeof(double)) != hipSuccess) {
     sk_config_destroy(cfg);
     return fail(SK_EHIP, "hipHostMalloc failed");

@@ -82,6 +82,8 @@ struct sk_config {
   std::vector<size_t> chunk_edge;            // chunk boundaries of the transfer in progress
   std::vector<hipEvent_t> cp_events;         // one per download chunk
   double host_timing[4] = {0, 0, 0, 0};      // last sk_kernel_values call: upload, march, download, total (ms)
+  bool expect_unsorted = false;              // the last device-resident input of unknown order (expect_n lags) was unsorted
+  long long expect_n = -1;
   long long last_n_steps = 0;                // steps of the last batched march on this config (0: none yet)
   int copy_threads = 0;                      // staging threads of this config (0: SK_COPY_THREADS / 8); sharded: cores / shards
   // joint march (sk_joint.cpp): grow-only buffers, one rocFFT plan per number of raw transforms

@@ -2366,16 +2366,28 @@ void launch_check_sorted(const double* xs, long long n, int* flags, hipStream_t 
 
 // keys (the bit pattern of a non-negative double orders like the double), identity permutation and -- for the bucket
 // sort -- the largest key of every workgroup (maxkey may be null)
+// info[0] = 1 if the input was not strictly increasing, info[1] = 1 if it holds a negative or NaN lag (plain stores of the
+// same value: no atomics) -- what k_check_sorted finds, for callers that sort without asking first
 __global__ void __launch_bounds__(256) k_make_keys(const double* xs, long long n, unsigned long long* keys, long long* idx,
-                                                   unsigned long long* maxkey) {
+                                                   unsigned long long* maxkey, int* info) {
   __shared__ unsigned long long sm[4];
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long k = 0ull;
+  bool bad = false, desc = false;
   if (i < n) {
     double x = xs[i];
     k = (x == 0.0) ? 0ull : (unsigned long long)__double_as_longlong(x);  // -0.0 == 0.0
     keys[i] = k;
     idx[i] = i;
+    bad = !(x >= 0.0);
+    desc = (i + 1 < n) && !(x < xs[i + 1]);
+  }
+  if (info) {
+    const bool ad = __any(desc), ab = __any(bad);
+    if ((threadIdx.x & 63) == 0) {
+      if (ad) info[0] = 1;
+      if (ab) info[1] = 1;
+    }
   }
   if (!maxkey) return;
   for (int off = 32; off > 0; off >>= 1) {
@@ -2681,8 +2693,10 @@ void sort_unique(const double* xs, long long n, double* uxs, long long* inv, lon
   size_t lib_bytes = temp_bytes - 6 * arr;
   size_t sb = lib_bytes;
   const int* overflow = nullptr;
+  int* info = (int*)((char*)d_n_unique + 16);  // [unsorted, invalid]: beside the count, read back with it
+  (void)hipMemsetAsync(d_n_unique, 0, 32, st);
   if (use_lib || n < 32768 || n >= 0x7fffffffll) {
-    hipLaunchKernelGGL(k_make_keys, dim3(nblk(n, 256)), dim3(256), 0, st, xs, n, keys_in, idx_in, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_make_keys, dim3(nblk(n, 256)), dim3(256), 0, st, xs, n, keys_in, idx_in, (unsigned long long*)nullptr, info);
     (void)rocprim::radix_sort_pairs(lib, sb, keys_in, keys_out, idx_in, idx_out, (size_t)n, 0, 64, st);
   } else {
     // `head` and `uid1` (adjacent) hold the scattered pairs until the buckets are sorted; the library region the small arrays
@@ -2691,7 +2705,7 @@ void sort_unique(const double* xs, long long n, double* uxs, long long* inv, lon
     int* starts = (int*)((char*)counts + align_up((size_t)(kBkN + 1) * sizeof(int)));
     int* table = (int*)((char*)starts + align_up((size_t)(kBkN + 1) * sizeof(int)));
     unsigned long long* wgmax = (unsigned long long*)table;  // read by k_bk_range before k_bk_hist overwrites the table
-    hipLaunchKernelGGL(k_make_keys, dim3(nblk(n, 256)), dim3(256), 0, st, xs, n, keys_in, idx_in, wgmax);
+    hipLaunchKernelGGL(k_make_keys, dim3(nblk(n, 256)), dim3(256), 0, st, xs, n, keys_in, idx_in, wgmax, info);
     hipLaunchKernelGGL(k_bk_range, dim3(1), dim3(1024), 0, st, wgmax, (int)nblk(n, 256), stt);
     const int nwg = (int)(nblk(n, 1024) < (unsigned)kBkWgs ? nblk(n, 1024) : (unsigned)kBkWgs);
     hipLaunchKernelGGL(k_bk_hist, dim3(nwg), dim3(1024), 0, st, keys_in, n, stt, table);
@@ -2718,15 +2732,18 @@ void sort_unique(const double* xs, long long n, double* uxs, long long* inv, lon
 }
 
 int sort_unique_sync(const double* xs, long long n, double* uxs, long long* inv, long long* d_n_unique, long long* h_nu,
-                     void* temp, size_t temp_bytes, hipStream_t st, long long* nu) {
+                     void* temp, size_t temp_bytes, hipStream_t st, long long* nu, int* was_unsorted, int* invalid) {
   for (int pass = 0; pass < 2; ++pass) {
     sort_unique(xs, n, uxs, inv, d_n_unique, temp, temp_bytes, st, pass == 1);
-    if (hipMemcpyAsync(h_nu, d_n_unique, sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+    if (hipMemcpyAsync(h_nu, d_n_unique, 3 * sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       return 1;
     if (*h_nu >= 0) break;
   }
   *nu = *h_nu;
+  const int* info = (const int*)(h_nu + 2);
+  if (was_unsorted) *was_unsorted = info[0];
+  if (invalid) *invalid = info[1];
   return *h_nu < 0 ? 1 : 0;
 }
 

@@ -47,3 +47,47 @@ def test_unsorted_invalid_lags_are_rejected(sk):
         x[1234] = bad
         with pytest.raises(sk.SpectralKernelsError):
             sk.kernel_values(cfg, x, k0=1.0)
+
+
+def test_device_resident_unsorted_lags_are_sorted_without_asking_from_the_second_call_on(sk):
+    # the first call of a config finds out (check + speculative first step); the next ones with as many lags sort at once,
+    # and the sort reports what the check would have: an invalid lag, or an input that was sorted after all
+    cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1.0, 1.0, 1.5), quadspec=(64, 4), tol=1e-7)
+    k0 = sk.compute_k0(cfg)
+    g = np.random.default_rng(5)
+    n = 60000
+    ref_cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1.0, 1.0, 1.5), quadspec=(64, 4), tol=1e-7)
+
+    def run(rs):
+        d_rs, d_ks, d_es = sk.DeviceArray.from_host(rs), sk.DeviceArray(n), sk.DeviceArray(n)
+        sk.kernel_values_device(cfg, d_rs.ptr, n, k0, d_ks.ptr, d_es.ptr)
+        sk.synchronize()
+        return d_ks.to_host(), d_es.to_host(), cfg.last_stats()
+
+    def expect(rs):
+        ux, inv = np.unique(rs, return_inverse=True)
+        ks, es = sk.kernel_values(ref_cfg, ux, k0=k0)
+        return ks[inv], es[inv]
+
+    syncs = []
+    for trial in range(3):  # unsorted three times: the second and third take the sort-first path
+        rs = g.uniform(0, 2, n)
+        ks, es, st = run(rs)
+        eks, ees = expect(rs)
+        assert np.array_equal(ks, eks) and np.array_equal(es, ees, equal_nan=True)
+        syncs.append(st["n_syncs"])
+    srt = np.sort(g.uniform(0, 2, n))           # sorted after all: still right, and the expectation ends
+    ks, es, st = run(srt)
+    eks, ees = expect(srt)
+    assert np.array_equal(ks, eks)
+    ks2, _, st2 = run(srt)                      # ... so this one is marched as it is
+    assert np.array_equal(ks2, eks) and st2["n_unique"] == n
+    rs = g.uniform(0, 2, n)
+    run(rs)                                     # unsorted again: found out by the check
+    bad = g.uniform(0, 2, n)
+    bad[777] = -1.0
+    with pytest.raises(sk.SpectralKernelsError):  # sort-first path: the sort reports the invalid lag
+        run(bad)
+    ks, es, _ = run(rs)                         # and the config is still usable
+    eks, _ = expect(rs)
+    assert np.array_equal(ks, eks)
