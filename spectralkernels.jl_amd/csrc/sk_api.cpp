@@ -395,6 +395,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   // one evaluation of the current (sub)panel with integrand g and Bessel order nu (dim > 1); raw != 0 stores
   // the panel sums instead of running the epilogue
   unsigned int stream_seq = 0;  // != 0: streaming phase of the batched march (see below)
+  bool gen_ahead = false;
   auto eval_pass = [&](int g, int nu, int raw, std::vector<double>& hv) -> int {
     if (cb) {
       int rc = upload_fvals(g, hv);
@@ -415,7 +416,8 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       { EvScope e(cfg, st, SK_K_INTERP); launch_interp_b(cfg->dc, cfg->d_ec, db, t & 1, n, st); }
       return SK_OK;
     }
-    { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, g, st); }
+    if (gen_ahead) gen_ahead = false;  // issued behind k_advance, ahead of the host round trip
+    else { EvScope e(cfg, st, SK_K_GEN); launch_gen(cfg->dc, db, mode, t, n, k0, ks0, g, st); }
     if (cfg->dc.dim == 1) {
       { EvScope e(cfg, st, SK_K_SPREAD); launch_spread(cfg->dc, cfg->d_ec, db, t & 1, st); }
       {
@@ -656,6 +658,14 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       // host closure: needs state_t (panel bounds) before the step can be generated
       const unsigned int seq = ++cfg->seq;
       launch_advance(cfg->dc, db, mode, t, n, k0, ks0, seq, st);
+      // dim > 1, catalogue SDF, no log factors: the node generation needs the device's state only (not the host's plan
+      // of the step): it runs while the status travels; a finished march makes it a no-op
+      gen_ahead = false;
+      if (!cb && !logw && cfg->dc.dim > 1) {
+        EvScope e(cfg, st, SK_K_GEN);
+        launch_gen(cfg->dc, db, SK_MODE_ASIS, t, n, k0, ks0, SK_G_DEFAULT, st);
+        gen_ahead = true;
+      }
       int rc = wait_status(cfg, seq, st);
       if (rc) return rc;
       if (check_flags && (cfg->h_status->flags[0] || cfg->h_status->flags[1])) return SK_OK;
@@ -665,7 +675,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         *cfg->h_scal = cfg->sdf(hs->b);  // pinned; the previous iteration's copy completed before its status block
         HIPCHK(hipMemcpyAsync(&db.state[t & 1].fb, cfg->h_scal, sizeof(double), hipMemcpyHostToDevice, st));
       }
-      launch_tail(cfg->dc, db, t & 1, st);
+      if (cb) launch_tail(cfg->dc, db, t & 1, st);  // catalogue SDFs: k_advance has fitted the tail already
       mode = SK_MODE_ASIS;
       lw_first = logw && hs->pp.jacobi;  // _a == 0 && p != 0 (src/quadrature.jl:185-186)
     }

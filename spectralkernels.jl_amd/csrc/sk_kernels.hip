@@ -522,6 +522,9 @@ __global__ void __launch_bounds__(64) k_advance(DevConst dc, DevBuffers db, int 
                                                  double ks0, unsigned int seq) {
   __shared__ DevState sh;
   step_state(sh, dc, db, mode, t, n, k0, ks0, blockIdx.x == 0);
+  // dim > 1, catalogue SDF: the tail fit of a new outer panel right here (the thread that published the state; program
+  // order) instead of a k_tail launch behind the host round trip
+  if (threadIdx.x == 0 && dc.dim > 1 && dc.sdf_kind != SK_SDF_CALLBACK && !sh.done) resolve_tail(db.state[t & 1], dc);
   if (dc.dim > 1 && !sh.done && threadIdx.x <= kHkMaxLevels) {
     // lags per level edge for the Hankel path's level planning: first active index with xs > r_hi / beta^l
     double edge = sh.pp.r_hi;
