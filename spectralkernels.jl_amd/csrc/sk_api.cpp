@@ -208,6 +208,7 @@ static hipEvent_t ev_get(sk_config* cfg) {
 // GPU fault can be attributed to a kernel (diagnostics only; serialises the pipeline).
 static const bool g_debug_sync = getenv("SK_DEBUG_SYNC") != nullptr;
 static const bool g_no_fuse = getenv("SK_NO_FUSE") != nullptr;  // diagnostics: separate k_gen and k_spread launches
+static const bool g_debug_hk = getenv("SK_DEBUG_HK") != nullptr;    // diagnostics: the plan of every Hankel step
 static const bool g_hk_serial = getenv("SK_HK_SERIAL") != nullptr;  // diagnostics: Hankel boxes on the march's stream
 static const bool g_no_stream = getenv("SK_NO_STREAM") != nullptr;  // diagnostics: rounds with k_advance throughout
 static const bool g_debug_batch = getenv("SK_DEBUG_BATCH") != nullptr;  // diagnostics: one step per round, every state printed
@@ -274,6 +275,33 @@ static int run_fft(sk_config* cfg, hipStream_t st) {
   void* in[1] = {cfg->db.fft};
   void* out[1] = {cfg->db.fft_out};
   FFTCHK(rocfft_execute(cfg->plan, in, out, cfg->info));
+  return SK_OK;
+}
+
+// Hankel path: the batched transform of the first nt series terms (both rules), in place in db.hk_fft
+static int run_fft_hk(sk_config* cfg, int nt, hipStream_t st) {
+  const int full = hk_terms(cfg->dc.w);
+  rocfft_plan plan = cfg->plan_hk;
+  rocfft_execution_info info = cfg->info_hk;
+  if (nt < full) {
+    if (!cfg->plan_hk_nt[nt]) {
+      size_t len2[1] = {(size_t)cfg->dc.n2};
+      FFTCHK(rocfft_plan_create(&cfg->plan_hk_nt[nt], rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+                                rocfft_precision_double, 1, len2, (size_t)2 * nt, nullptr));
+      size_t wb = 0;
+      FFTCHK(rocfft_plan_get_work_buffer_size(cfg->plan_hk_nt[nt], &wb));
+      FFTCHK(rocfft_execution_info_create(&cfg->info_hk_nt[nt]));
+      if (wb) {
+        HIPCHK(hipMalloc(&cfg->fft_work_hk_nt[nt], wb));
+        FFTCHK(rocfft_execution_info_set_work_buffer(cfg->info_hk_nt[nt], cfg->fft_work_hk_nt[nt], wb));
+      }
+    }
+    plan = cfg->plan_hk_nt[nt];
+    info = cfg->info_hk_nt[nt];
+  }
+  FFTCHK(rocfft_execution_info_set_stream(info, st));
+  void* in[1] = {cfg->db.hk_fft};
+  FFTCHK(rocfft_execute(plan, in, nullptr, info));
   return SK_OK;
 }
 
@@ -451,6 +479,18 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       bool boxes = false;
       if (cfg->hk_nb > 0) {
         auto n_of_z = [](double z) { return std::ceil(z + 9.0 * std::cbrt(z) + 14.0); };
+        // series terms: the default count is sized for z0 = 24 (hk_terms); from a larger first z, the fewest terms with
+        // the same first omitted term
+        const int nt_full = hk_terms(cfg->dc.w);
+        double ak[kHkTerms + 2];
+        ak[0] = 1.0;
+        for (int q = 1; q <= kHkTerms + 1; ++q) ak[q] = ak[q - 1] * (4.0 * nu * nu - (2.0 * q - 1.0) * (2.0 * q - 1.0)) / (8.0 * q);
+        const double thr = std::fabs(ak[nt_full]) / std::pow(kHkZ0, nt_full);
+        auto terms_for = [&](double z) {
+          for (int K = 2; K < nt_full; ++K)
+            if (std::fabs(ak[K]) / std::pow(z, K) <= thr) return K;
+          return nt_full;
+        };
         const double pa = hs->pp.pa;
         const long long nact = hs->hi - hs->ix1;
         hin.nu = nu;
@@ -486,12 +526,21 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
           double best = INFINITY;
           for (int l = 1; l < kHkMaxLevels; ++l) {
             const double beta = std::pow(kHkBeta, l), r_c = r_hi / beta;
-            const double om0 = kHkZ0 * beta / (2.0 * M_PI * r_hi);
+            double om0 = kHkZ0 * beta / (2.0 * M_PI * r_hi);
             if (om0 >= pb) break;  // nothing left for the series
+            const long long icnt = cfg->h_status->lvl_cnt[l];
+            // a panel that starts beyond om0 has no near sources; the series then runs from z >= 2 pi pa r_c > z0 on and
+            // needs fewer terms for the same truncation error
+            int nt = nt_full;
+            if (om0 <= pa) {
+              om0 = pa;
+              nt = terms_for(2.0 * M_PI * pa * r_c);
+            }
             const double fnear = om0 <= pa ? 0.0 : (om0 - pa) / (pb - pa);
             const double qn = fnear > 0.0 ? std::ceil(M_PI * om0 * (r_hi - r_c) / 96.0) : 0.0;
             double cost = 3.0 * (double)cfg->M * fnear * qn * kHkNodes;
-            const long long icnt = cfg->h_status->lvl_cnt[l];
+            // spread + FFT: 8.6 us per term at 196 608 sources; taps: 7.4 us per term and 1e6 lags; 1 us ~ 7e4 evaluations
+            cost += nt * (3.06 * 3.0 * (double)cfg->M + 0.52 * (double)(nact - icnt));
             int nb = 1, ngm = 0;
             double qi = 0.0;
             if (icnt > 0) {
@@ -503,7 +552,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
             if (qn + qi > (double)kHkQCap) continue;
             if (cost < best) {
               best = cost;
-              hin.has_far = 1; hin.r_c = r_c; hin.om0 = om0; hin.nb = nb; hin.ngm = ngm;
+              hin.has_far = 1; hin.r_c = r_c; hin.om0 = om0; hin.nb = nb; hin.ngm = ngm; hin.nt = nt;
               hin.Qn = (int)qn; hin.Q = (int)qi;
               hin.lag_cnt = icnt;
               boxes = true;
@@ -533,13 +582,16 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
           if ((size_t)hin.nb * hin.ngm > (size_t)4 * cfg->hk_ngmax) boxes = false;  // equivalent sources per interval the buffer holds
         }
       }
+      if (boxes && g_debug_hk)
+        fprintf(stderr, "[sk] hankel step: panel [%.6g, %.6g] r_hi %.6g  far %d r_c %.4g om0 %.5g nt %d  Qn %d  inner: lags %lld Q %d nb %d ngm %d\n",
+                hin.pa, hin.pb, hin.r_hi, hin.has_far, hin.r_c, hin.om0, hin.nt, hin.Qn, hin.lag_cnt, hin.Q, hin.nb, hin.ngm);
       if (boxes) {
         // the boxes (a chain of small launches) run beside the spread and the FFT, which do not depend on them; the
         // per-kernel event timing (sk_profile_enable) keeps everything on one stream
         const bool beside = hin.has_far && !cfg->profile && !g_hk_serial;
         if (beside) {  // both chains start at once: the spread is issued ahead of the (longer) chain of the boxes
           HIPCHK(hipEventRecord(cfg->fork_event, st));
-          launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, st);
+          launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, hin.nt, st);
           HIPCHK(hipStreamWaitEvent(cfg->side_stream, cfg->fork_event, 0));
           launch_hk_boxes(cfg->dc, db, hin, cfg->side_stream);
           HIPCHK(hipEventRecord(cfg->join_event, cfg->side_stream));
@@ -548,12 +600,11 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
           launch_hk_boxes(cfg->dc, db, hin, st);
         }
         if (hin.has_far) {
-          if (!beside) { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, st); }
+          if (!beside) { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, hin.nt, st); }
           {
             EvScope e(cfg, st, SK_K_FFT);
-            FFTCHK(rocfft_execution_info_set_stream(cfg->info_hk, st));
-            void* in[1] = {db.hk_fft};
-            FFTCHK(rocfft_execute(cfg->plan_hk, in, nullptr, cfg->info_hk));
+            int rcf = run_fft_hk(cfg, hin.nt, st);
+            if (rcf) return rcf;
           }
           if (beside) HIPCHK(hipStreamWaitEvent(st, cfg->join_event, 0));
           { EvScope e(cfg, st, SK_K_INTERP); launch_hk_far(cfg->dc, cfg->d_ec, db, hin, t & 1, n, raw, st); }
@@ -584,7 +635,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       hp.edge[L + 1] = 0.0;
       { EvScope e(cfg, st, SK_K_NEAR); launch_hk_near(cfg->dc, db, hp, st); }
       for (int l = 0; l < L; ++l) {
-        { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hp.om[l], st); }
+        { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hp.om[l], hk_terms(cfg->dc.w), st); }
         {
           EvScope e(cfg, st, SK_K_FFT);
           FFTCHK(rocfft_execution_info_set_stream(cfg->info_hk, st));
@@ -1294,6 +1345,11 @@ void sk_config_destroy(sk_config* cfg) {
   if (cfg->plan_seam) rocfft_plan_destroy(cfg->plan_seam);
   if (cfg->info_seam) rocfft_execution_info_destroy(cfg->info_seam);
   if (cfg->fft_work_seam) hipFree(cfg->fft_work_seam);
+  for (int q = 0; q <= kHkTerms; ++q) {
+    if (cfg->plan_hk_nt[q]) rocfft_plan_destroy(cfg->plan_hk_nt[q]);
+    if (cfg->info_hk_nt[q]) rocfft_execution_info_destroy(cfg->info_hk_nt[q]);
+    if (cfg->fft_work_hk_nt[q]) hipFree(cfg->fft_work_hk_nt[q]);
+  }
   if (cfg->plan_hk) rocfft_plan_destroy(cfg->plan_hk);
   if (cfg->info_hk) rocfft_execution_info_destroy(cfg->info_hk);
   if (cfg->fft_work_hk) hipFree(cfg->fft_work_hk);

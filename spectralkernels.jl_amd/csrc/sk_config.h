@@ -60,6 +60,10 @@ struct sk_config {
   rocfft_plan plan_hk = nullptr;   // batch 2*hk_terms(w), Hankel path
   void* fft_work_hk = nullptr;
   rocfft_execution_info info_hk = nullptr;
+  // the same transform with fewer series terms (batch 2 nt), created on first use
+  rocfft_plan plan_hk_nt[kHkTerms + 1] = {};
+  rocfft_execution_info info_hk_nt[kHkTerms + 1] = {};
+  void* fft_work_hk_nt[kHkTerms + 1] = {};
   double hk_a[kHkTerms], hk_a2[kHkTerms];  // a_k(nu) of the main order and of dim/2 (logw pass B)
   int hk_nb = 0;                   // 1: the Hankel path runs by boxes (sk_hankel_inner.inc); 0: level split only (SK_HK_LEVELS)
   int hk_ngmax = 0;                // moments per band the buffers hold

@@ -51,6 +51,7 @@ struct HkInner {
   int nu, nb, gs, Q, ngm;
   int Qn;                      // near box intervals (0: no near sources, or no far field at all)
   int has_far;                 // 0: the whole panel is one smooth box (r_c = r_hi, no NUFFT)
+  int nt;                      // series terms of this step (<= hk_terms(w))
   double escale;               // exponent e of the r^-e factor folded into the node values (dim/2 - 1; 0 in the raw passes)
   double r_c, ell, pa, pb;
   double om0, elln, r_hi;
@@ -300,7 +301,7 @@ void launch_bessel(const DevConst& dc, const DevBuffers& db, int slot, long long
 // logw first panel: combine the raw sums of passes A and B with the boundary term (src/quadrature.jl:189,224-225)
 void launch_lw_finish(const DevConst& dc, const DevBuffers& db, int slot, long long n, double B0, hipStream_t st);
 // far sources (w >= om) of one level: all series terms spread in one launch
-void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, double om, hipStream_t st);
+void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, double om, int nt, hipStream_t st);
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st);
 void launch_hk_boxes(const DevConst& dc, const DevBuffers& db, const HkInner& hi, hipStream_t st);
 void hk_series_fill(HkSeries& ser, const double* a, int nu);

@@ -993,8 +993,8 @@ k_spread(DevConst dc, const EsConst* ec, DevBuffers db, int slot_or_t, int mode,
 // in HBM.  Term k writes db.hk_fft + k*2*n2.
 template <int W>
 __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, const EsConst* ec, DevBuffers db, int slot,
-                                                                 double om) {
-  constexpr int NT = hk_terms(W);
+                                                                 double om, int nt) {
+  constexpr int NT = hk_terms(W);  // most terms (register and LDS budget); nt <= NT are generated
   constexpr int NB = 128;                       // sources per batch
   constexpr int NPART = kSpreadThreads / 64;    // waves
   constexpr int TPW = (NT + NPART - 1) / NPART; // terms per wave: k = part, part + NPART, ...
@@ -1011,7 +1011,7 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
   if ((int)blockIdx.x >= ntiles) {
     // zero padding of every term's FFT input: indices [n1 - n1/2, n2 - n1/2) of both rules
     const int64_t npad = n2 - n1;
-    for (int64_t g = ((int64_t)blockIdx.x - ntiles) * kSpreadThreads + tid; g < (int64_t)NT * 2 * npad;
+    for (int64_t g = ((int64_t)blockIdx.x - ntiles) * kSpreadThreads + tid; g < (int64_t)nt * 2 * npad;
          g += (int64_t)(gridDim.x - ntiles) * kSpreadThreads) {
       const int64_t kr = g / npad, off = g - kr * npad;  // kr = k*2 + rule
       db.hk_fft[kr * n2 + (n1 - n1 / 2) + off] = make_double2(0.0, 0.0);
@@ -1070,7 +1070,7 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
       }
 #pragma unroll
       for (int k = 0; k < NT; ++k) {
-        s_ck[k * NB + jj] = make_double2(scr, sci);
+        if (k < nt) s_ck[k * NB + jj] = make_double2(scr, sci);
         scr *= q;
         sci *= q;
       }
@@ -1086,7 +1086,7 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
 #pragma unroll
           for (int q = 0; q < TPW; ++q) {
             const int k = part + q * NPART;
-            if (k < NT) {
+            if (k < nt) {
               const double2 c = s_ck[k * NB + jj];
               ar[q] = fma(c.x, wv, ar[q]);
               ai[q] = fma(c.y, wv, ai[q]);
@@ -1107,7 +1107,7 @@ __global__ void __launch_bounds__(kSpreadThreads) k_spread_multi(DevConst dc, co
       xr += __shfl_xor(xr, off, 64);
       xi += __shfl_xor(xi, off, 64);
     }
-    if (k < NT && sub == 0 && cell < ncell)
+    if (k < nt && sub == 0 && cell < ncell)
       db.hk_fft[((int64_t)k * 2 + rule) * n2 + (l < 0 ? l + n2 : l)] = make_double2(xr * dcv, xi * dcv);
   }
 }
@@ -2091,11 +2091,11 @@ void launch_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, 
   SK_DISPATCH_W(dc.w, hipLaunchKernelGGL((k_spread<W, false>), dim3(tiles + 1), dim3(kSpreadThreads), 0, st, dc, ec, db,
                                          slot, 0, 0ll, 0.0, 0.0));
 }
-void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, double om, hipStream_t st) {
-  // the fixed-geometry spread, all asymptotic terms in one launch
+void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, double om, int nt, hipStream_t st) {
+  // the fixed-geometry spread, all asymptotic terms in one launch (nt <= hk_terms(w) of them)
   const unsigned tiles = (unsigned)(dc.ntiles[0] > dc.ntiles[1] ? dc.ntiles[0] : dc.ntiles[1]);
   SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_spread_multi<W>, dim3(tiles + 512), dim3(kSpreadThreads), 0, st, dc, ec, db,
-                                         slot, om));
+                                         slot, om, nt));
 }
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st) {
   if (hp.near_levels <= 0) return;
