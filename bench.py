@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement").
 import argparse
 import ctypes.util
 import json
+import math
 import os
 import shutil
 import sys
@@ -381,10 +382,16 @@ def main():
         mixj = json.load(open(os.path.join(ROOT, "profiles", "%s_interp_instmix.json" % ROUND)))
         mix = mixj.get(str(cfg.nufft_width)) if mixj.get("kernels_sha") == kernels_sha() else None
         if dom == "interp" and mix:
-            waves = 4.0 * (acc["interp"]["active_items"] / acc["interp"]["launches"]) / 256.0
-            issue_us = waves * mix["valu_per_wave"] * 4.0 / (1024 * 2.4e3)
-            roofline["valu_issue"] = {"valu_insts_per_wave": mix["valu_per_wave"], "fp64_insts_per_wave": mix["fp64_fma_add_mul_per_wave"],
-                                      "waves_per_launch": waves, "issue_us_at_peak_clock": issue_us,
+            # waves of one launch: 256 lags per workgroup of four waves, over the lags active in a step (a wave evaluates
+            # every panel of the step); issue cycles per wave: 4 per FP64 instruction, 2 per other vector instruction
+            # (16 / 32 lanes per clock and SIMD), 1024 SIMDs at the 2.4 GHz peak clock
+            waves = 4.0 * math.ceil(st["sum_active_steps"] / max(1, st["n_steps"]) / 256.0)
+            f64 = mix["fp64_fma_add_mul_per_wave"]
+            cyc = 4.0 * f64 + 2.0 * (mix["valu_per_wave"] - f64)
+            issue_us = waves * cyc / (1024 * 2.4e3)
+            roofline["valu_issue"] = {"valu_insts_per_wave": mix["valu_per_wave"], "fp64_insts_per_wave": f64,
+                                      "waves_per_launch": waves, "issue_cycles_per_wave": cyc,
+                                      "issue_us_at_peak_clock": issue_us,
                                       "frac_of_issue_peak": issue_us / rl["interp"]["avg_us"]}
     except Exception:
         pass
