@@ -2484,21 +2484,32 @@ __global__ void __launch_bounds__(1024) k_bk_hist(const unsigned long long* keys
   __syncthreads();
   for (int t = threadIdx.x; t < kBkN; t += blockDim.x) table[(size_t)blockIdx.x * kBkN + t] = h[t];
 }
-__global__ void __launch_bounds__(64) k_bk_colscan(int* table, int nwg, int* counts) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= kBkN) return;
+__global__ void __launch_bounds__(256) k_bk_colscan(int* table, int nwg, int* counts) {
+  // 64 buckets x 4 quarters of the rows per workgroup: local prefixes (16 independent loads in flight), quarter totals
+  // through LDS, then the offsets of the earlier quarters added in a second, independent pass
+  __shared__ int tot[4][64];
+  const int bl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + bl;
+  const int per = (nwg + 3) >> 2;
+  const int w0 = g * per, w1 = (w0 + per < nwg) ? w0 + per : nwg;
   int run = 0;
-  for (int w0 = 0; w0 < nwg; w0 += 16) {  // 16 independent loads in flight, then their prefixes
+  for (int w = w0; w < w1; w += 16) {
     int c[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) c[q] = (w0 + q < nwg) ? table[(size_t)(w0 + q) * kBkN + b] : 0;
+    for (int q = 0; q < 16; ++q) c[q] = (w + q < w1) ? table[(size_t)(w + q) * kBkN + b] : 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      if (w0 + q < nwg) table[(size_t)(w0 + q) * kBkN + b] = run;
+      if (w + q < w1) table[(size_t)(w + q) * kBkN + b] = run;
       run += c[q];
     }
   }
-  counts[b] = run;
+  tot[g][bl] = run;
+  __syncthreads();
+  int off = 0;
+  for (int q = 0; q < g; ++q) off += tot[q][bl];
+  if (g == 3) counts[b] = off + run;
+  if (off)
+    for (int w = w0; w < w1; ++w) table[(size_t)w * kBkN + b] += off;
 }
 // starts[b] = first slot of bucket b (exclusive scan); overflow if a bucket exceeds kBkCap
 __global__ void __launch_bounds__(1024) k_bk_scan(const int* counts, int* starts, BkState* stt) {
@@ -2548,8 +2559,10 @@ __global__ void __launch_bounds__(1024) k_bk_scatter(const unsigned long long* k
 // barriers (a workgroup per bucket with an LDS network spends its time in barriers and launch latency: 43-50 us; rocprim's
 // segmented sort 96 us plus a host round trip).
 template <int E>
-__device__ __forceinline__ void bk_sort_regs(const ulonglong2* rec, int lo, int cnt, unsigned long long* keys_out,
-                                             long long* idx_out) {
+// also: code[lo + t] = (rank of the pair's key among the bucket's distinct keys) * 2 + (first pair of that key); returns
+// the number of distinct keys (equal keys share a bucket, so the first pair of a bucket always opens a new key)
+__device__ __forceinline__ int bk_sort_regs(const ulonglong2* rec, int lo, int cnt, unsigned long long* keys_out,
+                                            long long* idx_out, int* code) {
   const int lane = threadIdx.x & 63;
   unsigned long long k[E];
   long long ix[E];
@@ -2601,30 +2614,46 @@ __device__ __forceinline__ void bk_sort_regs(const ulonglong2* rec, int lo, int 
       }
     }
   }
+  int heads = 0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int t = e * 64 + lane;
+    unsigned long long prev = __shfl_up(k[e], 1, 64);
+    if (e > 0) {
+      const unsigned long long last = __shfl(k[e - 1], 63, 64);
+      prev = lane == 0 ? last : prev;
+    }
+    const bool head = t < cnt && (t == 0 || k[e] != prev);
+    const unsigned long long m = __ballot(head);
+    const int rank = heads + __popcll(m & ((2ull << lane) - 1ull)) - 1;
+    heads += __popcll(m);
     if (t < cnt) {
       keys_out[lo + t] = k[e];
       idx_out[lo + t] = ix[e];
+      code[lo + t] = rank * 2 + (head ? 1 : 0);
     }
   }
+  return heads;
 }
 __global__ void __launch_bounds__(256) k_bk_sort_wave(const ulonglong2* rec, const int* starts, const BkState* stt,
-                                                      unsigned long long* keys_out, long long* idx_out) {
+                                                      unsigned long long* keys_out, long long* idx_out, int* code, int* ucount) {
   const int bkt = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lo = starts[bkt], cnt = starts[bkt + 1] - lo;
-  if (stt->overflow || cnt <= 0 || cnt > 512) return;  // wave-uniform
-  if (cnt <= 64) bk_sort_regs<1>(rec, lo, cnt, keys_out, idx_out);
-  else if (cnt <= 128) bk_sort_regs<2>(rec, lo, cnt, keys_out, idx_out);
-  else if (cnt <= 256) bk_sort_regs<4>(rec, lo, cnt, keys_out, idx_out);
-  else bk_sort_regs<8>(rec, lo, cnt, keys_out, idx_out);
+  if (stt->overflow || cnt > 512) return;  // wave-uniform (the larger buckets: k_bk_sort_big)
+  int heads = 0;
+  if (cnt <= 0) heads = 0;
+  else if (cnt <= 64) heads = bk_sort_regs<1>(rec, lo, cnt, keys_out, idx_out, code);
+  else if (cnt <= 128) heads = bk_sort_regs<2>(rec, lo, cnt, keys_out, idx_out, code);
+  else if (cnt <= 256) heads = bk_sort_regs<4>(rec, lo, cnt, keys_out, idx_out, code);
+  else heads = bk_sort_regs<8>(rec, lo, cnt, keys_out, idx_out, code);
+  if ((threadIdx.x & 63) == 0) ucount[bkt] = heads;
 }
 // k_bk_sort_big: the buckets of 513 .. kBkCap pairs, 64 buckets per workgroup (few or none qualify), network in LDS
 __global__ void __launch_bounds__(256) k_bk_sort_big(const ulonglong2* rec, const int* starts, const BkState* stt,
-                                                     unsigned long long* keys_out, long long* idx_out) {
+                                                     unsigned long long* keys_out, long long* idx_out, int* code, int* ucount) {
   __shared__ unsigned long long sk_[kBkCap];
   __shared__ long long si_[kBkCap];
+  __shared__ int s_part[256];
   if (stt->overflow) return;
   for (int bq = 0; bq < 64; ++bq) {
     const int bkt = blockIdx.x * 64 + bq;
@@ -2656,11 +2685,75 @@ __global__ void __launch_bounds__(256) k_bk_sort_big(const ulonglong2* rec, cons
         __syncthreads();
       }
     }
-    for (int t = threadIdx.x; t < cnt; t += 256) {
+    // distinct-key ranks: each thread a contiguous chunk, chunk totals scanned in LDS
+    const int chunk = (cnt + 255) / 256;
+    const int c0 = threadIdx.x * chunk, c1 = (c0 + chunk < cnt) ? c0 + chunk : cnt;
+    int hc = 0;
+    for (int t = c0; t < c1; ++t) hc += (t == 0 || sk_[t] != sk_[t - 1]) ? 1 : 0;
+    s_part[threadIdx.x] = hc;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const int v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    int rank = s_part[threadIdx.x] - hc - 1;
+    for (int t = c0; t < c1; ++t) {
+      const bool head = (t == 0 || sk_[t] != sk_[t - 1]);
+      rank += head ? 1 : 0;
       keys_out[lo + t] = sk_[t];
       idx_out[lo + t] = si_[t];
+      code[lo + t] = rank * 2 + (head ? 1 : 0);
     }
+    if (threadIdx.x == 255) ucount[bkt] = s_part[255];
     __syncthreads();
+  }
+}
+// first unique index of every bucket (exclusive scan of the distinct-key counts) and the number of unique lags; a bucket
+// sort that overflowed reports -1 (sort_unique_sync then sorts with the library)
+__global__ void __launch_bounds__(1024) k_bk_uscan(const int* ucount, int* ubase, const BkState* stt, long long* n_unique) {
+  __shared__ int part[1024];
+  if (stt->overflow) {
+    if (threadIdx.x == 0) *n_unique = -1;
+    return;
+  }
+  constexpr int PER = kBkN / 1024;
+  int loc[PER], sum = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    loc[q] = ucount[threadIdx.x * PER + q];
+    sum += loc[q];
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - sum;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    ubase[threadIdx.x * PER + q] = run;
+    run += loc[q];
+  }
+  if (threadIdx.x == 1023) *n_unique = run;
+}
+// unique lags and the inverse map, one wave per bucket (what k_heads / scan / k_scatter_unique do for the library sort)
+__global__ void __launch_bounds__(256) k_bk_finish(const unsigned long long* keys, const long long* perm, const int* code,
+                                                   const int* starts, const int* ubase, const BkState* stt, double* uxs,
+                                                   long long* inv) {
+  if (stt->overflow) return;
+  const int bkt = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int lo = starts[bkt], cnt = starts[bkt + 1] - lo;
+  const long long ub = ubase[bkt];
+  for (int t = lane; t < cnt; t += 64) {
+    const int c = code[lo + t];
+    const long long u = ub + (c >> 1);
+    if (c & 1) uxs[u] = __longlong_as_double((long long)keys[lo + t]);
+    inv[perm[lo + t]] = u;
   }
 }
 
@@ -2695,7 +2788,6 @@ void sort_unique(const double* xs, long long n, double* uxs, long long* inv, lon
   void* lib = base;
   size_t lib_bytes = temp_bytes - 6 * arr;
   size_t sb = lib_bytes;
-  const int* overflow = nullptr;
   int* info = (int*)((char*)d_n_unique + 16);  // [unsorted, invalid]: beside the count, read back with it
   (void)hipMemsetAsync(d_n_unique, 0, 32, st);
   if (use_lib || n < 32768 || n >= 0x7fffffffll) {
@@ -2712,26 +2804,25 @@ void sort_unique(const double* xs, long long n, double* uxs, long long* inv, lon
     hipLaunchKernelGGL(k_bk_range, dim3(1), dim3(1024), 0, st, wgmax, (int)nblk(n, 256), stt);
     const int nwg = (int)(nblk(n, 1024) < (unsigned)kBkWgs ? nblk(n, 1024) : (unsigned)kBkWgs);
     hipLaunchKernelGGL(k_bk_hist, dim3(nwg), dim3(1024), 0, st, keys_in, n, stt, table);
-    hipLaunchKernelGGL(k_bk_colscan, dim3(kBkN / 64), dim3(64), 0, st, table, nwg, counts);
+    hipLaunchKernelGGL(k_bk_colscan, dim3(kBkN / 64), dim3(256), 0, st, table, nwg, counts);
     hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, st, counts, starts, stt);
     ulonglong2* rec = (ulonglong2*)head;  // head and uid1 are adjacent: n 16-byte records
     hipLaunchKernelGGL(k_bk_scatter, dim3(nwg), dim3(1024), 0, st, keys_in, n, stt, table, starts, rec);
-    hipLaunchKernelGGL(k_bk_sort_wave, dim3(kBkN / 4), dim3(256), 0, st, rec, starts, stt, keys_out, idx_out);
-    hipLaunchKernelGGL(k_bk_sort_big, dim3(kBkN / 64), dim3(256), 0, st, rec, starts, stt, keys_out, idx_out);
-    // the flag outlives the scan below (which reuses the library region): keep a copy beside the result
-    overflow = &stt->overflow;
-  }
-  if (overflow) {
-    // heads / scan / scatter on unsorted data are harmless except for the scatter's indexed write, which checks the flag
-    // -- but the scan's temporary storage overlays BkState: move the flag into d_n_unique's neighbour first
-    (void)hipMemcpyAsync((char*)d_n_unique + 8, overflow, sizeof(int), hipMemcpyDeviceToDevice, st);
-    overflow = (const int*)((char*)d_n_unique + 8);
+    // distinct keys are ranked while the buckets are sorted: code in keys_in (free since the scatter), counts over `counts`
+    int* code = (int*)keys_in;
+    int* ucount = counts;  // the pair counts are in `starts` by now
+    int* ubase = (int*)idx_in;
+    hipLaunchKernelGGL(k_bk_sort_wave, dim3(kBkN / 4), dim3(256), 0, st, rec, starts, stt, keys_out, idx_out, code, ucount);
+    hipLaunchKernelGGL(k_bk_sort_big, dim3(kBkN / 64), dim3(256), 0, st, rec, starts, stt, keys_out, idx_out, code, ucount);
+    hipLaunchKernelGGL(k_bk_uscan, dim3(1), dim3(1024), 0, st, ucount, ubase, stt, d_n_unique);
+    hipLaunchKernelGGL(k_bk_finish, dim3(kBkN / 4), dim3(256), 0, st, keys_out, idx_out, code, starts, ubase, stt, uxs, inv);
+    return;
   }
   hipLaunchKernelGGL(k_heads, dim3(nblk(n, 256)), dim3(256), 0, st, keys_out, n, head);
   sb = lib_bytes;
   (void)rocprim::inclusive_scan(lib, sb, head, uid1, (size_t)n, rocprim::plus<long long>(), st);
   hipLaunchKernelGGL(k_scatter_unique, dim3(nblk(n, 256)), dim3(256), 0, st, keys_out, idx_out, uid1, n, uxs, inv,
-                     d_n_unique, overflow);
+                     d_n_unique, (const int*)nullptr);
 }
 
 int sort_unique_sync(const double* xs, long long n, double* uxs, long long* inv, long long* d_n_unique, long long* h_nu,
