@@ -2565,14 +2565,14 @@ __device__ __forceinline__ int bk_sort_regs(const ulonglong2* rec, int lo, int c
                                             long long* idx_out, int* code) {
   const int lane = threadIdx.x & 63;
   unsigned long long k[E];
-  long long ix[E];
+  int ix[E];  // the pair's index: n < 2^31 on this path (one shuffle instead of two)
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int t = e * 64 + lane;
     ulonglong2 r = make_ulonglong2(~0ull, 0x7fffffffffffffffull);
     if (t < cnt) r = rec[lo + t];
     k[e] = r.x;
-    ix[e] = (long long)r.y;
+    ix[e] = (int)r.y;
   }
   // stage loops are NOT unrolled (unrolled, the four instantiations are 90 KB of code and the kernel waits for its
   // instructions: 47 us); register-to-register exchanges need static indices, hence one body per distance 64, 128, 256
@@ -2586,7 +2586,7 @@ __device__ __forceinline__ int bk_sort_regs(const ulonglong2* rec, int lo, int c
         const bool sw = up ? (k[e] > k[f]) : (k[e] < k[f]);
         if (sw) {
           const unsigned long long tk = k[e]; k[e] = k[f]; k[f] = tk;
-          const long long ti = ix[e]; ix[e] = ix[f]; ix[f] = ti;
+          const int ti = ix[e]; ix[e] = ix[f]; ix[f] = ti;
         }
       }
     }
@@ -2604,7 +2604,7 @@ __device__ __forceinline__ int bk_sort_regs(const ulonglong2* rec, int lo, int c
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const unsigned long long ok = __shfl_xor(k[e], j, 64);
-        const long long oi = __shfl_xor(ix[e], j, 64);
+        const int oi = __shfl_xor(ix[e], j, 64);
         const int t = e * 64 + lane;
         const bool keep_min = ((t & j) == 0) == ((t & kk) == 0);
         if (keep_min ? (ok < k[e]) : (ok > k[e])) {
@@ -2629,7 +2629,7 @@ __device__ __forceinline__ int bk_sort_regs(const ulonglong2* rec, int lo, int c
     heads += __popcll(m);
     if (t < cnt) {
       keys_out[lo + t] = k[e];
-      idx_out[lo + t] = ix[e];
+      idx_out[lo + t] = (long long)ix[e];
       code[lo + t] = rank * 2 + (head ? 1 : 0);
     }
   }
