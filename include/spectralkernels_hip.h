@@ -74,7 +74,7 @@ typedef struct {
   int device;              /* HIP device ordinal; -1 = current device */
   int nufft_width;         /* 0 = choose from tol; else spreading width w in [4,16] */
   int hankel_min_lags;     /* dim >= 2: use the fast Hankel transform for >= this many unique lags, the direct
-                              Bessel-sum kernel below (0 = default 2048; -1 = always direct) */
+                              Bessel-sum kernel below (0 = default 8; -1 = always direct) */
   int sdf_dparam;          /* catalogue SDFs: 0 = the SDF itself; j >= 1 = its derivative with respect to
                               sdf_params[j-1] -- the integrands of kernel_sdf_derivatives (src/derivatives.jl:61-72),
                               evaluated on the device.  Matern: phi, rho, nu; exponential, gaussian: a. */

@@ -365,7 +365,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   const bool cb = (cfg->dc.sdf_kind == SK_SDF_CALLBACK);
   const bool logw = cfg->dc.logw != 0;
   // dim >= 2: fast Hankel transform (host-driven per step: the level split depends on r_hi) or direct sums
-  const int hk_min = cfg->args.hankel_min_lags == 0 ? 2048 : cfg->args.hankel_min_lags;
+  const int hk_min = cfg->args.hankel_min_lags == 0 ? kHkDefaultMinLags : cfg->args.hankel_min_lags;
   const bool hankel = cfg->dc.dim > 1 && hk_min > 0 && n >= hk_min;
   // the host needs state_t before each step: callback SDFs (node values), Hankel (level split), logw (the first
   // panel takes two passes and a boundary term, src/quadrature.jl:186-228)

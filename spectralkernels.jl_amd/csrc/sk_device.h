@@ -19,6 +19,10 @@ constexpr int kHkNodes = 160;    // Chebyshev nodes of the near-field interpolan
 constexpr int kHkSplit = 16;     // workgroups sharing one near-field node sum
 constexpr int kHkMaxLevels = 12; // lag levels (ratio kHkBeta) incl. the innermost near-only one
 constexpr double kHkZ0 = 24.0;
+// dim >= 2: lag sets of at least this many lags take the fast Hankel transform (hankel_min_lags = 0).  Round 3: 8 (was 2048):
+// with the transform by boxes the direct Bessel sums lose at every size -- 46 ms against 0.38 ms per call at 100 lags on the
+// default rule (tools/diag/hankel_cutoff.py); they remain for the smallest sets and as the reference's own slow branch.
+constexpr int kHkDefaultMinLags = 8;
 constexpr double kHkBeta = 8.0;
 
 // One step of the Hankel path: lag levels l = 0..L (level L is near-only).  Level l < L covers lags in

@@ -36,6 +36,38 @@ size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 namespace {
 
+// What a joint call accepts, whichever way it is then evaluated (joint march, or one fast-Hankel march per integrand for
+// the larger lag sets in dim >= 2): the same inputs are rejected with the same codes at every size.
+int joint_check_args(sk_config* const* cfgs, size_t ncfg) {
+  if (!cfgs || ncfg == 0 || !cfgs[0]) return fail(SK_EINVAL, "null config");
+  if (ncfg > (size_t)kJointMax) return fail(SK_EINVAL, "at most 8 integrands per joint march");
+  const sk_config* c0 = cfgs[0];
+  if (c0->args.derivative || c0->args.logw)
+    return fail(SK_EINVAL, "joint march: the first config must be the plain kernel (it provides the shared nodes)");
+  int n_logw = 0, ntr = 0;
+  for (size_t t = 0; t < ncfg; ++t) {
+    const sk_config* c = cfgs[t];
+    if (!c) return fail(SK_EINVAL, "null config");
+    const sk_config_args& a = c->args;
+    if (c->device != c0->device) return fail(SK_EINVAL, "joint march: configs must live on one device");
+    if (a.dim != c0->args.dim) return fail(SK_EINVAL, "joint march: the configs must have one dim");
+    // catalogue SDFs are evaluated on the device; host callbacks once per panel for all integrands -- not mixed
+    if ((a.sdf_kind == SK_SDF_CALLBACK) != (c0->args.sdf_kind == SK_SDF_CALLBACK))
+      return fail(SK_EUNSUPPORTED, "joint march: all integrands catalogue SDFs or all host callbacks");
+    if (a.sdf_kind == SK_SDF_CALLBACK && a.logw)
+      return fail(SK_EUNSUPPORTED, "joint march: logw with a callback SDF (use sk_kernel_values_multi)");
+    if (c->m != c0->m || c->k != c0->k || a.tol != c0->args.tol || a.alpha != c0->args.alpha || a.criteria != c0->args.criteria ||
+        a.has_tail != c0->args.has_tail || (a.has_tail && a.tail != c0->args.tail) || c->dc.w != c0->dc.w)
+      return fail(SK_EINVAL, "joint march: quadspec, tol, alpha, convergence_criteria, tail and NUFFT width must agree");
+    if (a.logw && a.sdf_dparam) return fail(SK_EUNSUPPORTED, "joint march: logw with a parameter-derivative integrand");
+    // one boundary factor jB0 per march (DevState): a second logw integrand would be given the first one's
+    if (a.logw && n_logw++) return fail(SK_EUNSUPPORTED, "joint march: at most one logw integrand");
+    ntr += a.logw ? 2 : 1;
+    if (ntr > kJointTr) return fail(SK_EINVAL, "joint march: too many raw transforms");
+  }
+  return SK_OK;
+}
+
 // The joint march behind both entries.  Lags: a host array `xs` (staged upload) or, if xs == nullptr, `d_lags_in`
 // already on the device (any order).  On return *d_vals / *d_errs point at nt x n device arrays in INPUT order
 // (row t = integrand t), valid until the next joint call on cfgs[0].
@@ -299,8 +331,10 @@ extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const
   if (cfgs && ncfg && cfgs[0] && cfgs[0]->args.dim > 1) {
     // dim >= 2: the joint march evaluates direct Bessel sums (O(lags x nodes) per panel, the reference's own branch
     // for its 136-lag Jacobian tests); big lag sets go through the fast Hankel transform, one march per integrand
-    const int hk_min = cfgs[0]->args.hankel_min_lags == 0 ? 2048 : cfgs[0]->args.hankel_min_lags;
+    const int hk_min = cfgs[0]->args.hankel_min_lags == 0 ? kHkDefaultMinLags : cfgs[0]->args.hankel_min_lags;
     if (hk_min > 0 && n >= (size_t)hk_min) {
+      const int rcc = joint_check_args(cfgs, ncfg);
+      if (rcc) return rcc;
       std::vector<double> k0s(ncfg, k0);
       return sk_kernel_values_multi(cfgs, ncfg, xs, n, k0s.data(), param_derivative, vals_out, errs_out);
     }

@@ -113,3 +113,24 @@ def test_random_configs_boxes_vs_direct_sums(sk, seed):
     from hankel_stress import run_seed
     desc, ok, detail = run_seed(sk, seed)
     assert ok, desc + ": " + detail
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 40, 300])
+def test_default_cutover_and_tiny_lag_sets(sk, n):
+    # hankel_min_lags = 0: eight lags and more take the transform by boxes (the direct sums lose at every size:
+    # tools/diag/hankel_cutoff.py); same values as the direct kernel either side of the cut-over, also for one or two lags
+    kw = dict(dim=2, tol=1e-8, quadspec=(256, 16))
+    sdf = sk.SDF.matern(*PARMS, 2)
+    rs = np.sort(np.random.default_rng(n).uniform(0.01, 1.2, n))
+    auto = sk.AdaptiveKernelConfig(sdf, **kw)
+    direct = sk.AdaptiveKernelConfig(sdf, hankel_min_lags=-1, **kw)
+    boxes = sk.AdaptiveKernelConfig(sdf, hankel_min_lags=1, **kw)
+    k0 = sk.compute_k0(auto)
+    ka, ea = sk.kernel_values(auto, rs, k0=k0)
+    kd, ed = sk.kernel_values(direct, rs, k0=k0)
+    kb, eb = sk.kernel_values(boxes, rs, k0=k0)
+    assert np.abs(ka - kd).max() / k0 <= 5e-13 and np.abs(kb - kd).max() / k0 <= 5e-13
+    assert auto.last_stats()["n_panels"] == direct.last_stats()["n_panels"] == boxes.last_stats()["n_panels"]
+    # which path ran: the direct kernel reproduces itself bit for bit, the transform does not reproduce the direct sums
+    same = np.array_equal(ka, kd)
+    assert same == (n < 8) or np.array_equal(kb, kd)

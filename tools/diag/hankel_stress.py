@@ -1,11 +1,11 @@
 """Random dim >= 2 configurations: the Hankel path by boxes against the device's direct Bessel sums (hankel_min_lags=-1),
-same lags.  Prints every seed; exit code 1 on a mismatch.  usage: hankel_stress.py [first seed] [count]"""
+same lags.  Prints every seed; exit code 1 on a mismatch.  usage: hankel_stress.py [first seed] [count] [fewest lags] [most lags]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
-def run_seed(sk, seed):
+def run_seed(sk, seed, nlo=2100, nhi=12000):
     """(description, ok, detail) of one random configuration."""
     g = np.random.default_rng(seed)
     dim = int(g.choice([2, 2, 2, 4, 6]))
@@ -15,7 +15,7 @@ def run_seed(sk, seed):
     derivative = bool(g.random() < 0.25)
     alpha = float(g.choice([0.0, 0.0, 0.5, 1.5])) if dim == 2 else 0.0
     prm = (float(g.uniform(0.3, 2.0)), float(10.0 ** g.uniform(-1.5, 0.7)), float(g.uniform(0.4, 2.5)))
-    n = int(g.integers(2100, 12000))
+    n = int(g.integers(nlo, nhi))
     top = float(10.0 ** g.uniform(-2, 1))
     kind = int(g.integers(0, 3))
     if kind == 0:
@@ -55,9 +55,11 @@ if __name__ == "__main__":
     import spectralkernels_jl_amd as sk
     s0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    nlo = int(sys.argv[3]) if len(sys.argv) > 3 else 2100
+    nhi = int(sys.argv[4]) if len(sys.argv) > 4 else 12000
     bad = 0
     for seed in range(s0, s0 + cnt):
-        desc, ok, detail = run_seed(sk, seed)
+        desc, ok, detail = run_seed(sk, seed, nlo, nhi)
         print("%s: %s %s" % (desc, detail, "ok" if ok else "MISMATCH"), flush=True)
         bad += 0 if ok else 1
     print("mismatches: %d" % bad)
