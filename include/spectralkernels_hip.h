@@ -169,7 +169,8 @@ int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs
  * equal quadspec / tol / alpha / criteria / tail, at most one logw integrand; one k0 for all, as the reference passes
  * it (src/derivatives.jl:57,71,81).  dim 1: type-3 NUFFT with one transform per integrand; even dim >= 2: the direct
  * Bessel sums of src/quadrature.jl:145-160 with J_nu(2 pi w r) evaluated once per (lag, node) for all integrands (lag
- * sets of hankel_min_lags and more take one fast-Hankel march per integrand instead).  SDFs: all catalogue entries
+ * sets of hankel_min_lags and more -- 8 by default -- take one fast-Hankel march per integrand instead, here and in
+ * sk_kernel_jacobian_pairs).  SDFs: all catalogue entries
  * (incl. sdf_dparam), evaluated on the device, or all host callbacks, each called once per panel on all its nodes
  * (no logw integrand then).  vals_out / errs_out: ncfg x n. */
 int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, double k0,

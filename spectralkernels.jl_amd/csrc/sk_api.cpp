@@ -1652,6 +1652,45 @@ int kernel_values_pairs_range(sk_config* cfg, const double* pts, size_t npts, in
   if (!rc) rc = d2h_doubles2(cfg, vals_out, errs_out, d + count, count, st);
   return rc;
 }
+// One march per config on lags that are already on the device (any order, e.g. pairwise lags): what sk_kernel_values_multi
+// does for a host array.  *d_vals / *d_errs: ncfg x n device arrays in input order, valid until the next multi / pairs call
+// on cfgs[0].  (The dim >= 2 Jacobian entry: one fast-Hankel march per integrand beats the joint march's direct Bessel
+// sums at every size.)
+int multi_device_core(sk_config* const* cfgs, size_t ncfg, const double* d_lags, size_t n, double k0,
+                          const int* param_derivative, double** d_vals, double** d_errs) {
+  sk_config* c0 = cfgs[0];
+  HIPCHK(hipSetDevice(c0->device));
+  hipStream_t st = c0->own_stream;
+  const size_t a8 = ((n * 8 + 255) / 256) * 256;
+  const size_t tb = sort_unique_temp_bytes((long long)n);
+  int rc = ensure_dev(&c0->d_aux, &c0->aux_bytes, (4 + 2 * ncfg) * a8 + tb + 512);
+  if (rc) return rc;
+  char* buf = (char*)c0->d_aux;
+  double* uxs = (double*)buf;
+  long long* inv = (long long*)(buf + a8);
+  double* ks = (double*)(buf + 2 * a8);
+  double* errs = (double*)(buf + 3 * a8);
+  double* outv = (double*)(buf + 4 * a8);
+  double* oute = outv + ncfg * n;
+  long long* d_nu = (long long*)(buf + (4 + 2 * ncfg) * a8);
+  void* tmp = (char*)d_nu + 256;
+  long long nu = 0;
+  int was_unsorted = 1, bad_lags = 0;
+  if (sort_unique_sync(d_lags, (long long)n, uxs, inv, d_nu, c0->h_nuniq, tmp, tb, st, &nu, &was_unsorted, &bad_lags))
+    return fail(SK_EHIP, "sort failed");
+  if (bad_lags) return fail(SK_EINVAL, "lags must be non-negative and finite");
+  for (size_t c = 0; c < ncfg; ++c) {
+    rc = kernel_values_device_order(cfgs[c], uxs, (size_t)nu, k0, param_derivative ? param_derivative[c] : 0, ks, errs, st,
+                                    SK_ORDER_SORTED);
+    if (rc) return rc;
+    launch_gather(ks, errs, inv, (long long)n, outv + c * n, oute + c * n, st);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  *d_vals = outv;
+  *d_errs = oute;
+  return SK_OK;
+}
+
 }  // namespace sk
 
 extern "C" {

@@ -140,4 +140,7 @@ enum { SK_ORDER_UNKNOWN = 0, SK_ORDER_SORTED = 1, SK_ORDER_UNSORTED = 2, SK_ORDE
 int h2d_doubles(sk_config* cfg, double* d_dst, const double* src, size_t cnt, hipStream_t st, int* order);
 int d2h_doubles2(sk_config* cfg, double* dst_a, double* dst_b, const double* d_src, size_t cnt_each, hipStream_t st);
 int d2h_doubles(sk_config* cfg, double* dst, const double* d_src, size_t cnt, hipStream_t st);
+// sk_api.cpp: one march per config on device-resident lags of any order (ncfg x n results on the device, input order)
+int multi_device_core(sk_config* const* cfgs, size_t ncfg, const double* d_lags, size_t n, double k0,
+                      const int* param_derivative, double** d_vals, double** d_errs);
 }  // namespace sk

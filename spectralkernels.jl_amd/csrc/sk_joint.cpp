@@ -424,9 +424,17 @@ extern "C" int sk_kernel_jacobian_pairs(sk_config* const* cfgs, size_t ncfg, con
   HIPCHK(hipMemcpy(d_map, hmap.data(), hmap.size() * sizeof(int), hipMemcpyHostToDevice));
   launch_pair_lags(d_pts, (long long)npts, pdim, (const long long*)d_pairs, (long long)npairs, d_lags, st);
   double *dv = nullptr, *de = nullptr;
-  rc = joint_core(cfgs, ncfg, nullptr, d_lags, npairs, k0, pd.data(), &dv, &de, extra_bytes, &extra);
-  if (rc) return rc;
-  if (extra != (void*)c0->d_joint) return fail(SK_EHIP, "internal error: joint buffers moved");
+  const int hk_min = c0->args.hankel_min_lags == 0 ? kHkDefaultMinLags : c0->args.hankel_min_lags;
+  if (c0->args.dim > 1 && hk_min > 0 && npairs >= (size_t)hk_min) {
+    // dim >= 2: one fast-Hankel march per integrand (the joint march sums Bessel functions directly)
+    rc = joint_check_args(cfgs, ncfg);
+    if (!rc) rc = multi_device_core(cfgs, ncfg, d_lags, npairs, k0, pd.data(), &dv, &de);
+    if (rc) return rc;
+  } else {
+    rc = joint_core(cfgs, ncfg, nullptr, d_lags, npairs, k0, pd.data(), &dv, &de, extra_bytes, &extra);
+    if (rc) return rc;
+    if (extra != (void*)c0->d_joint) return fail(SK_EHIP, "internal error: joint buffers moved");
+  }
   if (ncols > 0) {
     launch_jac_assemble(dv, (long long)npairs, (int)ncfg, d_map, d_dlag, nwarp, t_warp, ncols, d_jac, st);
     rc = d2h_doubles(c0, jac_out, d_jac, npairs * (size_t)ncols, st);

@@ -329,3 +329,11 @@ def test_jacobian_pairs_dim2_matches_the_joint_march(sk, oracle):
     for q in range(2):
         assert np.abs(jac[:, q] - vj[3] * dlag[:, q]).max() <= 1e-10 * max(1.0, np.abs(vj[3] * dlag[:, q]).max())
     assert np.abs(vals - oracle.matern_cov(lags, prm, d=2)).max() / k0 <= 10 * 1e-10
+    # both evaluations of the entry: one fast-Hankel march per integrand (default from 8 pairs on) and the joint march
+    # with direct Bessel sums (hankel_min_lags = -1)
+    dkw = dict(hankel_min_lags=-1, **kw)
+    dcfgs = [sk.AdaptiveKernelConfig(f, **dkw), sk.AdaptiveKernelConfig(f.d(1), **dkw), sk.AdaptiveKernelConfig(f.d(2), **dkw),
+             sk.AdaptiveKernelConfig(f, derivative=True, **dkw)]
+    dvals, djac = sk.kernel_jacobian_pairs(dcfgs, [0, 1, 1, 2], [0, 2, 3, 0], wpts, pairs, k0, dlag=dlag, warp_cols=[0, 1], ncols=4)
+    assert np.abs(vals - dvals).max() <= 1e-12 * k0
+    assert np.abs(jac - djac).max() <= 1e-11 * max(1.0, np.abs(djac).max())
