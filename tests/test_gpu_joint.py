@@ -197,12 +197,21 @@ def test_joint_march_dim2_nll_2d_integrands(sk, oracle):
     lags = _warped_lags((1.5, 0.1))
     prm = (1.0, rng_, nu)
     f = sk.SDF.matern(*prm, 2)
-    kw = dict(dim=2, tol=tol)
+    kw = dict(dim=2, tol=tol, hankel_min_lags=-1)  # the joint march itself (by default 8 lags and more go through Hankel marches)
     cfgs = [sk.AdaptiveKernelConfig(f, **kw), sk.AdaptiveKernelConfig(f.d(1), **kw), sk.AdaptiveKernelConfig(f.d(2), **kw),
             sk.AdaptiveKernelConfig(f, derivative=True, **kw)]
     pds = [False, True, True, False]
     k0 = float(oracle.matern_cov(0.0, prm, d=2))
     vj, ej = sk.kernel_values_joint(cfgs, lags, k0, param_derivative=pds)
+    # the default evaluation of the same call: one fast-Hankel march per integrand
+    hkw = dict(dim=2, tol=tol)
+    hcfgs = [sk.AdaptiveKernelConfig(f, **hkw), sk.AdaptiveKernelConfig(f.d(1), **hkw), sk.AdaptiveKernelConfig(f.d(2), **hkw),
+             sk.AdaptiveKernelConfig(f, derivative=True, **hkw)]
+    vh, eh = sk.kernel_values_joint(hcfgs, lags, k0, param_derivative=pds)
+    for t in range(4):
+        s = max(k0, np.abs(vj[t][lags > 0]).max())
+        assert np.abs(vh[t] - vj[t]).max() <= 10 * tol * s, t
+        assert np.array_equal(np.isnan(eh[t]), np.isnan(ej[t]))
     st = cfgs[0].last_stats()
     assert st["n_unique"] == np.unique(lags).size and st["n_panels"] >= 1
     sep = _separate(sk, cfgs, lags, k0, pds)
@@ -244,7 +253,7 @@ def test_joint_march_dim2_singular_with_logw(sk, oracle):
     lags = np.unique(_warped_lags((0.8, 4.1)))
     prm = (1.0, 1.0, nu)
     f = sk.SDF.matern(*prm, 2)
-    kw = dict(dim=2, alpha=alpha, tol=tol)
+    kw = dict(dim=2, alpha=alpha, tol=tol, hankel_min_lags=-1)  # the joint march itself
     cfgs = [sk.AdaptiveKernelConfig(f, **kw), sk.AdaptiveKernelConfig(f.d(2), **kw),
             sk.AdaptiveKernelConfig(f, derivative=True, **kw), sk.AdaptiveKernelConfig(f, logw=True, **kw)]
     pds = [False, True, False, True]
@@ -270,7 +279,7 @@ def test_joint_march_with_callback_sdfs(sk, oracle):
     rs = np.sort(np.r_[0.0, np.random.default_rng(8).uniform(0.0, 1.1, 700)])
     for dim, quadspec, lagset in ((1, (256, 16), rs), (2, (128, 8), rs[::5])):
         f = sk.SDF.matern(*parms, dim)
-        kw = dict(dim=dim, quadspec=quadspec, tol=1e-8)
+        kw = dict(dim=dim, quadspec=quadspec, tol=1e-8, hankel_min_lags=-1)  # dim 2: the joint march's own kernels
         cat = [sk.AdaptiveKernelConfig(f, **kw), sk.AdaptiveKernelConfig(f, derivative=True, **kw),
                sk.AdaptiveKernelConfig(f.d(1), **kw), sk.AdaptiveKernelConfig(f.d(2), **kw)]
         cbs = [sk.AdaptiveKernelConfig(lambda w: f(w), sdf="callback", **kw),
