@@ -564,22 +564,22 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
           hin.ell = hin.Q > 0 ? hin.r_c / (double)hin.Q : hin.r_c;
           hin.elln = hin.Qn > 0 ? (r_hi - hin.r_c) / (double)hin.Qn : r_hi;
           const int qtot = hin.Q + hin.Qn;
-          if (qtot > cfg->hk_qalloc) {  // grow the interval buffers (rare: the counts grow with the panel index)
-            int qa = cfg->hk_qalloc ? cfg->hk_qalloc : 64;
-            while (qa < qtot) qa *= 2;
+          // interval buffers (grow only; rare: the counts grow with the panel index): equivalent sources of the inner
+          // box, node values and Chebyshev coefficients of both boxes
+          const size_t wb = ((sizeof(double2) * (size_t)hin.Q * 2 * hin.nb * hin.ngm + 255) / 256) * 256;
+          const size_t vb = ((sizeof(double) * (size_t)qtot * 2 * kHkNodes + 255) / 256) * 256;
+          if (wb + 2 * vb > cfg->hk_qbytes) {
             HIPCHK(hipStreamSynchronize(st));
             if (cfg->hk_qbuf) HIPCHK(hipFree(cfg->hk_qbuf));
             cfg->hk_qbuf = nullptr;
-            cfg->hk_qalloc = 0;
-            const size_t wb = sizeof(double2) * (size_t)qa * 2 * cfg->hk_ngmax * 4;  // nb x ngm <= 4 hk_ngmax (see below)
-            const size_t vb = sizeof(double) * (size_t)qa * 2 * kHkNodes;
-            HIPCHK(hipMalloc(&cfg->hk_qbuf, wb + 2 * vb));
-            cfg->hk_qalloc = qa;
-            db.hk_w = (double2*)cfg->hk_qbuf;
-            db.hk_v = (double*)((char*)cfg->hk_qbuf + wb);
-            db.hk_c2 = (double*)((char*)cfg->hk_qbuf + wb + vb);
+            cfg->hk_qbytes = 0;
+            const size_t want = (wb + 2 * vb) + (wb + 2 * vb) / 2 + (1u << 20);
+            HIPCHK(hipMalloc(&cfg->hk_qbuf, want));
+            cfg->hk_qbytes = want;
           }
-          if ((size_t)hin.nb * hin.ngm > (size_t)4 * cfg->hk_ngmax) boxes = false;  // equivalent sources per interval the buffer holds
+          db.hk_w = (double2*)cfg->hk_qbuf;
+          db.hk_v = (double*)((char*)cfg->hk_qbuf + wb);
+          db.hk_c2 = (double*)((char*)cfg->hk_qbuf + wb + vb);
         }
       }
       if (boxes && g_debug_hk)

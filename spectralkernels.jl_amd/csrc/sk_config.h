@@ -67,7 +67,7 @@ struct sk_config {
   double hk_a[kHkTerms], hk_a2[kHkTerms];  // a_k(nu) of the main order and of dim/2 (logw pass B)
   int hk_nb = 0;                   // 1: the Hankel path runs by boxes (sk_hankel_inner.inc); 0: level split only (SK_HK_LEVELS)
   int hk_ngmax = 0;                // moments per band the buffers hold
-  int hk_qalloc = 0;               // lag intervals the buffers hold (grow only)
+  size_t hk_qbytes = 0;            // bytes of hk_qbuf (grow only)
   void* hk_qbuf = nullptr;         // hk_w / hk_v / hk_c2
   rocfft_execution_info info = nullptr;
   void* fft_work = nullptr;
