@@ -45,8 +45,11 @@ def run_seed(sk, seed, nlo=2100, nhi=12000):
     (kb, eb, pb, cb), (kd, ed, pd, cd) = res
     if cb is not None or cd is not None:
         return desc, cb == cd, "errors %s / %s" % (cb, cd)
-    d = float(np.nanmax(np.abs(kb - kd)) / abs(k0))
-    de = float(np.nanmax(np.abs(eb - ed)) / abs(k0))
+    # (dim > 2: compute_k0, like the reference's, integrates w^(dim/2) S without the (pi w)^nu / nu! of the small-r limit and
+    # can be orders below K(0); the values themselves set the scale then)
+    scale = max(abs(k0), float(np.nanmax(np.abs(kd))))
+    d = float(np.nanmax(np.abs(kb - kd)) / scale)
+    de = float(np.nanmax(np.abs(eb - ed)) / scale)
     ok = pb == pd and d <= max(1e-3 * tol, 2e-12) and np.array_equal(np.isnan(eb), np.isnan(ed))
     return desc, bool(ok), "panels %d / %d  dK %.2e  derr %.2e" % (pb, pd, d, de)
 
