@@ -174,3 +174,25 @@ def test_launch_floor_probe_is_safe_on_any_config_state(sk):
             assert all(0.5 < v < 200.0 for v in f.values()), f
         assert np.abs(ks2 - np.pi / 2 * (1 + 2 * np.pi * rs) * np.exp(-2 * np.pi * rs)).max() <= 1e-7
         assert np.array_equal(ks, ks2[:3]) or np.abs(ks - ks2[:3]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("kind,prm,kw,mk", [
+    # every panel retires lags (the C3 pattern): the config switches to the one-panel kernels after its first march
+    ("matern", (2.14, 0.97, 0.89), dict(alpha=0.4, quadspec=(256, 16)), lambda: 10.0 ** np.linspace(-8, -2, 20000)),
+    # runs of outer panels (the C5 pattern): the full batch width stays
+    ("matern", (2.14, 0.97, 0.89), dict(tol=1e-12, quadspec=(256, 16)), lambda: np.linspace(0.0, 5.1, 20001)),
+])
+def test_automatic_batch_width_does_not_change_the_results(sk, kind, prm, kw, mk):
+    rs = mk()
+    auto = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), **kw)
+    one = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), batch_panels=1, **kw)
+    k0 = sk.compute_k0(auto)
+    ref = sk.kernel_values(one, rs, k0=k0)
+    sched = _sched(one)
+    for call in range(4):  # the first call probes with the full width, the later ones run what it chose
+        k, e = sk.kernel_values(auto, rs, k0=k0)
+        assert _sched(auto) == sched, call
+        assert np.nanmax(np.abs(k - ref[0])) <= 2e-13 * abs(k0) and np.array_equal(np.isnan(e), np.isnan(ref[1])), call
+        if call:
+            assert np.array_equal(k, prev[0]) and np.array_equal(e, prev[1], equal_nan=True), call
+        prev = (k, e)
