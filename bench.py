@@ -34,7 +34,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-ROUND = "r03"
+ROUND = "r04"
 
 WORKLOADS = {
     # name: (sdf kind, params, config kwargs, r-grid builder, k0, truth)
@@ -124,6 +124,61 @@ def timed(fn, steps, warmup, fence):
     return time.perf_counter() - t0
 
 
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves, as a CHILD process
+    (python -m torch.distributed.run, rendezvous on 127.0.0.1), issued before this process has imported the HIP
+    library or torch -- never an exec, never after a GPU call -- and hand back the child's exit code.  The ranks
+    inherit stdout: rank 0's JSON line is the one line this invocation prints."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def plumbing_only(args, w, sk, skdist, dist, rank, world):
+    """Everything of a multi-rank run but the march (no device needed): rendezvous, the cooperative K(0) all-reduce
+    (host quadrature, sk_host_compute_k0_part), this rank's share of the r-set, the barriers and the per-rank gather
+    that the real run uses; one JSON line on rank 0 with `value` null.  tests/test_dist_cpu.py drives it through the
+    self-launch door (`python bench.py --gpus 2 --backend gloo --plumbing-only`)."""
+    from spectralkernels_jl_amd import api
+    kind, prm = w["sdf"]
+    kw = dict(w["kw"])
+    a, _, _ = api._make_args(f=getattr(sk.SDF, kind)(*prm), df=None, dim=kw.get("dim", 1), alpha=kw.get("alpha", 0.0),
+                             tol=kw["tol"], derivative=False, logw=False, convergence_criteria="both", tail=None,
+                             quadspec=kw.get("quadspec", (4096, 16)), device=-1, nufft_width=0)
+
+    class ArgsOnly:  # shared_k0 needs the argument block only
+        _args = a
+
+    k0 = skdist.shared_k0(ArgsOnly, dist, None)
+    rs = shard_grid(w, rank, world, args.shard)
+    if dist is not None:
+        import torch
+        dist.barrier()
+        t = torch.tensor([float(rs.size), float(rs[0]), float(rs[-1])], dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rows = [x.numpy() for x in allt]
+        dist.barrier()
+    else:
+        rows = [np.array([float(rs.size), rs[0], rs[-1]])]
+    if rank == 0:
+        print(json.dumps({"metric": "r-targets/sec at tol=%g" % kw["tol"], "value": None, "unit": "r-targets/s",
+                          "n_gpus": world, "plumbing_only": True, "k0": k0, "backend": args.backend if dist is not None else None,
+                          "config": {"workload": args.workload + ": " + w["desc"], "sharding": args.shard},
+                          "per_rank": [{"rank": i, "lags": int(r[0]), "r_min": r[1], "r_max": r[2]} for i, r in enumerate(rows)]}))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,14 +194,20 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend at N > 1: nccl (= RCCL over xGMI; the driver's runs) or gloo "
                          "(rehearsal of the multi-rank plumbing with the ranks sharing the visible GPUs)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="rehearsal of the multi-rank plumbing without a device (CPU test tier): rendezvous, the K(0) "
+                         "all-reduce, the r-set split, barriers and the per-rank gather run; no march is launched and "
+                         "`value` is null")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # the driver's form for N = 1 (`python bench.py --gpus N`) must work for N > 1 too
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     dist = torch = None
     if world > 1:
         # torch (and with it RCCL) only in the multi-process case; it is imported before the HIP library so that
@@ -165,6 +226,8 @@ def main():
     from spectralkernels_jl_amd import dist as skdist
 
     w = WORKLOADS[args.workload]
+    if args.plumbing_only:
+        return plumbing_only(args, w, sk, skdist, dist, rank, world)
     kind, prm = w["sdf"]
     if prm is None:  # C3: normalise K(0) = 1 with the closed form (scripts/singular_matern_demo.jl:21)
         from scipy import special
@@ -243,11 +306,12 @@ def main():
                           "split_ms": {k: round(v, 4) for k, v in tm.items()}, "unique_lags": cfg.last_stats()["n_unique"]}
             return out["r"]
 
-        # the reference's contract first: sorted pageable lags in, two fresh vectors out (from the API's pinned pool)
-        hv, _ = leg("fresh_result_vectors", rs)
+        # the reference's contract first: sorted pageable lags in, two fresh ordinary (pageable) vectors out -- the
+        # headline of this span; then the same with the vectors taken from the API's capped pinned pool
+        hv, _ = leg("fresh_pageable_result_vectors", rs, results="pageable")
         host_err = float(np.abs(np.asarray(hv) - ks).max() / abs(k0))
         del hv
-        leg("fresh_pageable_result_vectors", rs, results="pageable")
+        leg("fresh_pinned_pool_result_vectors", rs, results="pinned")
         leg("reused_result_vectors", rs, into=(np.empty(n), np.empty(n)))
         prng = np.random.default_rng(7)
         perm = prng.permutation(n)
@@ -258,12 +322,13 @@ def main():
         px, pk, pe = sk.pinned_empty(n), sk.pinned_empty(n), sk.pinned_empty(n)
         px[:] = rs
         leg("all_pinned_arrays", px, into=(pk, pe))
-        head = legs["fresh_result_vectors"]
+        head = legs["fresh_pageable_result_vectors"]
         host = {"span": "host_to_host",
                 "what": "sk_kernel_values: pageable host array in, two host arrays out (src/adaptive.jl:95-108), %d steps.  "
-                        "Headline = fresh_result_vectors: the two result vectors are new per call, as the reference returns "
-                        "them, and come from the API's pool of pinned vectors; other legs: fresh pageable vectors / "
-                        "caller-provided reused vectors / permuted input with duplicates / all three arrays pinned" % hsteps,
+                        "Headline = fresh_pageable_result_vectors: the two result vectors are new ordinary (pageable) numpy "
+                        "vectors per call, as the reference returns them; other legs: fresh vectors from the API's capped "
+                        "pool of pinned vectors / caller-provided reused vectors / permuted input with duplicates / all "
+                        "three arrays pinned" % hsteps,
                 "ms_per_step": head["ms_per_step"], "value": head["value"], "unit": "r-targets/s",
                 "GB/s_effective": head["GB/s_effective"], "legs": legs,
                 "max_abs_diff_vs_device_leg_over_k0": host_err,
@@ -461,6 +526,13 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                "scaling": "strong" if args.workload == "C4" and world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic", "span": "device_resident",
+               # `value` is the device-resident span (lags in HBM when the timed region starts, the bench contract);
+               # SURVEY 8(d) / BASELINE.md 2.3 quote the metric host entry -> results in host memory: that figure of the
+               # same run is baseline_span_value (= host_to_host.value: fresh pageable result vectors), PCIe-inclusive
+               "value_span_matches_baseline": False,
+               "baseline_span": "host_to_host",
+               "baseline_span_value": host["value"] if host is not None else None,
+               "baseline_span_ms_per_step": host["ms_per_step"] if host is not None else None,
                "config": {"workload": args.workload + ": " + w["desc"], "lags_per_gpu": n,
                           "sharding": "r-set %s over ranks, K(0) all-reduce at set-up only" % args.shard,
                           "nufft_width": cfg.nufft_width},

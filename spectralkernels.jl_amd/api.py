@@ -73,6 +73,7 @@ class SDF:
 
 
 _CRIT = {"both": 0, "panel": 1, "tails": 2}
+_WARNED = {}  # warnings given once per process
 
 # probe frequencies: the first eleven solve for / verify the parameters; the rest reach into the range a march visits
 # (panels end at m k / (2 r), up to ~1e10 for the lags of BASELINE config 3) so that a closure with a cutoff, a band
@@ -138,8 +139,10 @@ def _make_args(f, df, dim, alpha, tol, derivative, logw, convergence_criteria, t
                hankel_min_lags=0, sdf="auto", batch_panels=0):
     if not isinstance(f, SDF):
         rec = recognize_sdf(f, dim) if sdf == "auto" else None
-        if rec is not None:
-            # the reference treats f as a black box (src/adaptive.jl:3): say so when it is not evaluated as one
+        if rec is not None and not _WARNED.get("recognized"):
+            # the reference treats f as a black box (src/adaptive.jl:3): say so when it is not evaluated as one --
+            # once per process (fitting loops rebuild configs every iteration)
+            _WARNED["recognized"] = True
             warnings.warn("AdaptiveKernelConfig: the SDF closure matches the device catalogue (%s, parameters %s) at %d "
                           "probe frequencies up to %.1e and is evaluated on the device; pass sdf=\"callback\" to have the "
                           "closure itself called in batches." % (
@@ -205,6 +208,13 @@ class AdaptiveKernelConfig:
         code = _check(lib.sk_config_create(C.byref(h), C.byref(args)))
         if code == L.SK_WARN_QUADSPEC:  # src/adaptive.jl:38
             warnings.warn(L.last_error())
+        if derivative and tol < 1e-9 and not _WARNED.get("deriv_tol"):
+            # a defect of the reference's algorithm that this library reproduces: the tail fit
+            # uses S where the K' integrand decays like w S(w) (src/adaptive.jl:204-229), so lags retire early
+            _WARNED["deriv_tol"] = True
+            warnings.warn("AdaptiveKernelConfig: derivative=true with tol < 1e-9: the truncation estimate of "
+                          "src/adaptive.jl:204-229 fits S(w) although the K' integrand decays like w S(w); results "
+                          "follow the reference's algorithm but may stop ~1000 tol short of the exact K'(r).")
         self._h = h
         p, c = C.c_double(), C.c_double()
         m, k, w = C.c_int64(), C.c_int64(), C.c_int()
@@ -286,12 +296,15 @@ def kernel_values(config, xs, k0=None, param_derivative=False, verbose=False, re
     """kernel_values(config, xs; k0, param_derivative, verbose) -> (vals, errs)
     src/adaptive.jl:95-108.  xs: host array (any order, duplicates allowed).  The two result vectors are fresh per
     call, as in the reference; results="pinned" (default) takes them from a pool of pinned vectors for large n
-    (_PinnedPool), results="pageable" from numpy."""
+    (_PinnedPool) while the pinned bytes callers still hold stay under the pool's cap (SK_PINNED_RESULT_BYTES, 256 MiB
+    by default; 0 switches the pool off) and from numpy beyond it; results="pageable": always numpy."""
     xs = np.ascontiguousarray(xs, dtype=np.float64)
     n = xs.size
+    vals = errs = None
     if results == "pinned" and n >= 4096:
-        vals, errs = pooled_pinned_empty(n), pooled_pinned_empty(n)
-    else:
+        vals = pooled_pinned_empty(n, or_none=True)
+        errs = pooled_pinned_empty(n, or_none=True) if vals is not None else None
+    if vals is None or errs is None:
         vals, errs = np.empty(n), np.empty(n)
     _check(L.load().sk_kernel_values(config._h, xs.ctypes.data_as(C.c_void_p), n, 0.0 if k0 is None else float(k0),
                                      0 if k0 is None else 1, int(bool(param_derivative)),
@@ -490,18 +503,28 @@ class _PinnedPool:
     MAX_PER_SIZE, MAX_BYTES = 8, 1 << 30
 
     def __init__(self):
+        import os
         self.free, self.bytes = {}, 0
+        # pinned bytes in callers' hands: a vector only comes back when its holder drops it, so without a cap a
+        # caller that keeps many results pins host memory without bound
+        self.outstanding = 0
+        self.max_outstanding = int(os.environ.get("SK_PINNED_RESULT_BYTES", str(256 << 20)))
 
-    def take(self, nbytes):
+    def take(self, nbytes, or_none=False):
+        if or_none and self.outstanding + nbytes > self.max_outstanding:
+            return None
         lst = self.free.get(nbytes)
         if lst:
             self.bytes -= nbytes
+            self.outstanding += nbytes
             return lst.pop()
         p = C.c_void_p()
         _check(L.load().sk_host_alloc(C.byref(p), nbytes))
+        self.outstanding += nbytes
         return p.value
 
     def give(self, ptr, nbytes):
+        self.outstanding -= nbytes
         lst = self.free.setdefault(nbytes, [])
         if len(lst) < self.MAX_PER_SIZE and self.bytes + nbytes <= self.MAX_BYTES:
             lst.append(ptr)
@@ -524,12 +547,15 @@ class _PooledOwner:
             pass
 
 
-def pooled_pinned_empty(n):
-    """float64 ndarray of length n from the pinned result-vector pool (see _PinnedPool)."""
+def pooled_pinned_empty(n, or_none=False):
+    """float64 ndarray of length n from the pinned result-vector pool (see _PinnedPool); or_none: None instead of a
+    vector when the pinned bytes still held by callers would exceed the pool's cap."""
     n = int(n)
     nbytes = 8 * max(n, 1)
     nbytes = (nbytes + 4095) & ~4095
-    ptr = _POOL.take(nbytes)
+    ptr = _POOL.take(nbytes, or_none)
+    if ptr is None:
+        return None
     buf = (C.c_double * max(n, 1)).from_address(ptr)
     buf._sk_owner = _PooledOwner(ptr, nbytes)
     return np.frombuffer(buf, dtype=np.float64, count=n)

@@ -11,7 +11,8 @@ module SpectralKernelsHIP
 
 export AdaptiveKernelConfig, kernel_values, kernel_values!, kernel_values_multi, kernel_values_joint, kernel_values_pairs,
        kernel_jacobian_pairs, build_dense_cov_matrix, compute_k0, gen_derivative_config, gen_new_sdf_config, recognize_sdf,
-       pinned_vector, ShardedKernelConfig, MaternSDF, ExponentialSDF, GaussianSDF, sdf_derivative, check_abi
+       pinned_vector, ShardedKernelConfig, MaternSDF, ExponentialSDF, GaussianSDF, sdf_derivative, check_abi,
+       kernel_values_device!, kernel_values_pairs_device!, set_split!, last_shard_stats
 
 const LIB = get(ENV, "SPECTRALKERNELS_HIP_LIB",
                 joinpath(@__DIR__, "..", "libspectralkernels_hip.so"))
@@ -180,7 +181,8 @@ function AdaptiveKernelConfig(f; df=nothing, dim=1, alpha=0.0, tol::Float64=1e-8
   if !(f isa Union{MaternSDF,ExponentialSDF,GaussianSDF}) && sdf == :auto
     rec = recognize_sdf(f, dim)
     if !isnothing(rec)
-      @warn "AdaptiveKernelConfig: the SDF closure matches the device catalogue ($(rec)) at $(length(PROBES)) probe frequencies up to $(PROBES[end]) and is evaluated on the device; pass sdf=:callback to have the closure itself called in batches."
+      # once per session: fitting loops rebuild configs every iteration
+      @warn "AdaptiveKernelConfig: the SDF closure matches the device catalogue ($(rec)) at $(length(PROBES)) probe frequencies up to $(PROBES[end]) and is evaluated on the device; pass sdf=:callback to have the closure itself called in batches." maxlog=1
       onsdf = rec
     end
   end
@@ -199,6 +201,8 @@ function AdaptiveKernelConfig(f; df=nothing, dim=1, alpha=0.0, tol::Float64=1e-8
   h = Ref{Ptr{Cvoid}}(C_NULL)
   code = _check(ccall((:sk_config_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{SkConfigArgs}), h, args))
   code == 100 && @warn(_last_error())                       # src/adaptive.jl:38
+  # a defect of the reference's algorithm that this library reproduces (DESIGN.md section 4)
+  (derivative && tol < 1e-9) && @warn "AdaptiveKernelConfig: derivative=true with tol < 1e-9: the truncation estimate of src/adaptive.jl:204-229 fits S(w) although the K' integrand decays like w S(w); results follow the reference's algorithm but may stop ~1000 tol short of the exact K'(r)." maxlog=1
   m = Ref{Int64}(0); k = Ref{Int64}(0); p = Ref{Cdouble}(0.0); c = Ref{Cdouble}(0.0)
   ccall((:sk_config_info, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}, Ref{Int64}, Ref{Int64}, Ptr{Cint}),
         h[], p, c, m, k, C_NULL)
@@ -267,41 +271,98 @@ function kernel_values!(vals::Vector{Float64}, errs::Vector{Float64}, cfg::Adapt
   (vals, errs)
 end
 
-# Result vectors: the reference RETURNS two fresh Vectors (src/adaptive.jl:105-107).  Fresh pageable ones cost a page
-# fault per 4 KB plus a staging copy (1.5 ms for the 16 MB of 10^6 lags, against 0.3 ms of DMA), so large results come
-# from a pool of pinned vectors: handed out here, returned by their finalizer when the caller drops them, reused by later
-# calls -- already mapped, already pinned, written by DMA directly.
+# Result vectors: the reference RETURNS two fresh, ordinary Vectors (src/adaptive.jl:105-107) -- growable, owned by the GC --
+# and so does kernel_values by default.  Fresh pageable vectors cost a page fault per 4 KB plus a staging copy (1.4 ms for
+# the 16 MB of 10^6 lags, against 0.3 ms of DMA); `results=:pinned` takes large results from a pool of pinned vectors
+# instead: handed out here, returned by their finalizer when the caller drops them, reused by later calls -- already mapped,
+# already pinned, written by DMA directly.  Such vectors wrap foreign memory (`own=false`): `push!` / `resize!` on them
+# fail, which is why the pool is opt-in.  The pinned bytes that callers still hold are capped (POOL_MAX_OUTSTANDING); beyond
+# the cap ordinary Vectors are returned.
 const _POOL = Dict{Int,Vector{Ptr{Cvoid}}}()
 const _POOL_LOCK = ReentrantLock()
+const _POOL_OUTSTANDING = Ref{Int}(0)
+const POOL_MAX_OUTSTANDING = Ref{Int}(parse(Int, get(ENV, "SK_PINNED_RESULT_BYTES", string(256 << 20))))
+function _pool_return(v, p::Ptr{Cvoid}, nbytes::Int)
+  # finalizers must not block: a task switch inside the GC is an error.  If the lock is busy, try again at the next collection.
+  if !trylock(_POOL_LOCK)
+    finalizer(w -> _pool_return(w, p, nbytes), v)
+    return nothing
+  end
+  keep = try
+    _POOL_OUTSTANDING[] -= nbytes
+    lst = get!(_POOL, nbytes, Ptr{Cvoid}[])
+    length(lst) < 8 ? (push!(lst, p); true) : false
+  finally
+    unlock(_POOL_LOCK)
+  end
+  keep || ccall((:sk_host_free, LIB), Cint, (Ptr{Cvoid},), p)
+  nothing
+end
 function _pooled_vector(n::Integer)
   nbytes = (8*max(n, 1) + 4095) & ~4095
-  p = lock(_POOL_LOCK) do
+  (ok, p) = lock(_POOL_LOCK) do
+    _POOL_OUTSTANDING[] + nbytes > POOL_MAX_OUTSTANDING[] && return (false, C_NULL)
+    _POOL_OUTSTANDING[] += nbytes
     lst = get!(_POOL, nbytes, Ptr{Cvoid}[])
-    isempty(lst) ? C_NULL : pop!(lst)
+    (true, isempty(lst) ? C_NULL : pop!(lst))
   end
+  ok || return Vector{Float64}(undef, n)
   if p == C_NULL
     r = Ref{Ptr{Cvoid}}(C_NULL)
     _check(ccall((:sk_host_alloc, LIB), Cint, (Ref{Ptr{Cvoid}}, Csize_t), r, nbytes))
     p = r[]
   end
   v = unsafe_wrap(Vector{Float64}, Ptr{Float64}(p), n; own=false)
-  finalizer(v) do _
-    keep = lock(_POOL_LOCK) do
-      lst = get!(_POOL, nbytes, Ptr{Cvoid}[])
-      length(lst) < 8 ? (push!(lst, p); true) : false
-    end
-    keep || ccall((:sk_host_free, LIB), Cint, (Ptr{Cvoid},), p)
-  end
+  finalizer(w -> _pool_return(w, p, nbytes), v)
   v
 end
 
 # src/adaptive.jl:95-108
 function kernel_values(cfg::AdaptiveKernelConfig, xs::AbstractVector{Float64};
-                       k0=nothing, param_derivative=false, verbose=false)
+                       k0=nothing, param_derivative=false, verbose=false, results::Symbol=:pageable)
   x = xs isa Vector{Float64} ? xs : Vector{Float64}(xs)
   n = length(x)
-  (vals, errs) = n >= 4096 ? (_pooled_vector(n), _pooled_vector(n)) : (Vector{Float64}(undef, n), Vector{Float64}(undef, n))
+  (vals, errs) = (results == :pinned && n >= 4096) ? (_pooled_vector(n), _pooled_vector(n)) :
+                                                     (Vector{Float64}(undef, n), Vector{Float64}(undef, n))
   kernel_values!(vals, errs, cfg, x; k0=k0, param_derivative=param_derivative, verbose=verbose)
+end
+
+"""
+    kernel_values_device!(d_vals, d_errs, cfg, d_xs, n; k0, param_derivative=false, stream=C_NULL)
+
+The same computation on HBM-resident arrays (sk_kernel_values_device): `d_xs`, `d_vals`, `d_errs` are device pointers
+on the config's device (e.g. `pointer(::ROCArray{Float64})`), any order / duplicates allowed; `k0` is required
+(`compute_k0(cfg)`).  Returns when the results are complete on `stream`.  What src/adaptive.jl:95-108 would be for a
+caller that keeps its lags on the GPU.
+"""
+function kernel_values_device!(d_vals::Ptr, d_errs::Ptr, cfg::AdaptiveKernelConfig, d_xs::Ptr, n::Integer;
+                               k0, param_derivative=false, stream::Ptr=C_NULL)
+  GC.@preserve cfg begin
+    _check(ccall((:sk_kernel_values_device, LIB), Cint,
+                 (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Cdouble, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}),
+                 cfg.handle, d_xs, n, Float64(k0), param_derivative ? 1 : 0, d_vals, d_errs, stream))
+  end
+  nothing
+end
+
+"""
+    kernel_values_pairs_device!(d_vals, d_errs, cfg, d_pts, npts, pdim, d_pairs, npairs; k0, ...)
+
+sk_kernel_values_pairs_device: the lags `norm(pts[j] - pts[k])` of HBM-resident points (row-major npts x pdim) and
+zero-based index pairs (`d_pairs == C_NULL`: the dense list "0 then all i < j" of src/utils.jl:43-46) are formed,
+deduplicated and marched on the device; values / errors in pair order (src/model.jl:64-65,76).
+"""
+function kernel_values_pairs_device!(d_vals::Ptr, d_errs::Ptr, cfg::AdaptiveKernelConfig, d_pts::Ptr, npts::Integer,
+                                     pdim::Integer, d_pairs::Ptr, npairs::Integer; k0, param_derivative=false,
+                                     stream::Ptr=C_NULL)
+  GC.@preserve cfg begin
+    _check(ccall((:sk_kernel_values_pairs_device, LIB), Cint,
+                 (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Cint, Ptr{Int64}, Csize_t, Cdouble, Cint, Ptr{Cdouble}, Ptr{Cdouble},
+                  Ptr{Cvoid}),
+                 cfg.handle, d_pts, npts, pdim, d_pairs, npairs, Float64(k0), param_derivative ? 1 : 0, d_vals, d_errs,
+                 stream))
+  end
+  nothing
 end
 
 function _multi(sym, cfgs, xs, k0arg, param_derivative)
@@ -453,6 +514,53 @@ function kernel_values(sh::ShardedKernelConfig, xs::AbstractVector{Float64}; k0=
                  param_derivative ? 1 : 0, vals, errs))
   end
   (vals, errs)
+end
+
+
+"Split of the sorted unique lag set over the shards (sk_sharded_set_split): `:blocked` contiguous blocks, `:strided` every ns-th lag (equal panel schedules)."
+function set_split!(sh::ShardedKernelConfig, split::Symbol)
+  split in (:blocked, :strided) || error("split must be :blocked or :strided")
+  _check(ccall((:sk_sharded_set_split, LIB), Cint, (Ptr{Cvoid}, Cint), sh.handle, split == :strided ? 1 : 0))
+  sh
+end
+
+# kernel_values on the lags of point pairs with the pair list cut into one block per device
+# (sk_kernel_values_pairs_sharded; src/model.jl:64-65, src/utils.jl:41-64): BASELINE config 4 in one call.
+# pairs === nothing: the dense list "0 then all i < j".
+function kernel_values_pairs(sh::ShardedKernelConfig, pts::AbstractVector,
+                             pairs::Union{Nothing,AbstractVector{<:Tuple{Integer,Integer}}}=nothing;
+                             k0=nothing, param_derivative=false)
+  pdim = length(first(pts))
+  p    = Matrix{Float64}(undef, pdim, length(pts))            # column-major pdim x npts == row-major npts x pdim
+  for (j, pt) in enumerate(pts), d in 1:pdim
+    p[d, j] = pt[d]
+  end
+  npts = length(pts)
+  if isnothing(pairs)
+    (n, ix, npairs) = (1 + npts*(npts - 1) ÷ 2, Int64[], 0)
+  else
+    ix = Matrix{Int64}(undef, 2, length(pairs))
+    for (e, (j, k)) in enumerate(pairs)
+      ix[1, e] = j - 1; ix[2, e] = k - 1
+    end
+    (n, npairs) = (length(pairs), length(pairs))
+  end
+  vals = Vector{Float64}(undef, n); errs = Vector{Float64}(undef, n)
+  GC.@preserve sh begin
+    _check(ccall((:sk_kernel_values_pairs_sharded, LIB), Cint,
+                 (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Cint, Ptr{Int64}, Csize_t, Cdouble, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
+                 sh.handle, p, npts, pdim, isnothing(pairs) ? Ptr{Int64}(C_NULL) : pointer(ix), npairs,
+                 isnothing(k0) ? 0.0 : Float64(k0), isnothing(k0) ? 0 : 1, param_derivative ? 1 : 0, vals, errs))
+  end
+  (vals, errs)
+end
+
+"Per shard of the last call (sk_sharded_last): panel statistics, wall time in ms and the block [lo, hi) it marched."
+function last_shard_stats(sh::ShardedKernelConfig, shard::Integer)
+  st = Ref(SkStats(0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0)); ms = Ref{Cdouble}(0.0); lo = Ref{Int64}(0); hi = Ref{Int64}(0)
+  _check(ccall((:sk_sharded_last, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{SkStats}, Ref{Cdouble}, Ref{Int64}, Ref{Int64}),
+               sh.handle, shard, st, ms, lo, hi))
+  (stats=st[], ms=ms[], lo=lo[], hi=hi[])
 end
 
 end # module

@@ -87,3 +87,52 @@ def test_shard_bounds_cover():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def _json_lines(out):
+    import json
+    lines = []
+    for ln in out.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                lines.append(json.loads(ln))
+            except ValueError:
+                pass
+    return lines
+
+
+@pytest.mark.parametrize("door", ["self_launch", "torchrun"])
+def test_bench_gpus2_gloo_through_both_doors(door):
+    """`python bench.py --gpus 2` (the driver's form for N = 1) must itself start the two ranks -- a child
+    torch.distributed.run, never an exec -- and relay rank 0's ONE JSON line; the launcher form stays.  The march is
+    left out (--plumbing-only: no device here); rendezvous, the K(0) all-reduce, the r-set split and the gathers run."""
+    pytest.importorskip("torch")
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = ["--gpus", "2", "--backend", "gloo", "--plumbing-only", "--workload", "C2", "--shard", "strided"]
+    if door == "self_launch":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + tail
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["plumbing_only"] and j["value"] is None and j["backend"] == "gloo"
+    assert abs(j["k0"] - np.pi / 2) < 1e-9  # the two halves of the K(0) quadrature, summed by the all-reduce
+    assert [p["lags"] for p in j["per_rank"]] == [10 ** 6, 10 ** 6]
+    # strided split: both ranks see the whole r-range (hence the same panel schedule)
+    assert all(p["r_min"] < 2e-6 and p["r_max"] > 0.99 for p in j["per_rank"])
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"], env=env,
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode != 0 and "does not match" in (r.stderr + r.stdout)

@@ -496,7 +496,7 @@ def test_stress_derivative_tol1e10_within_the_oracles_own_spread(sk, oracle, see
     derivative=true at tol 1e-10: ~10^4 panels with per-lag contributions at the convergence threshold.  The oracle itself
     moves by `spread` when its thresholds shift by 1e-4 relative (tests/test_oracle_pinning.py); HIP must sit inside that
     spread and be as close to the closed form as the oracle is."""
-    from seed27 import stress_case
+    from stress_cases import stress_case
     rs, k0, mk, truth = stress_case(oracle, seed, offset)
     oks, _, otr = oracle.kernel_values(mk(oracle, nthreads=8), rs, k0=k0, return_trace=True)
     spread = 0.0

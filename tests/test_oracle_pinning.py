@@ -271,7 +271,7 @@ def test_derivative_high_accuracy_regime_is_unstable_in_the_oracle_itself(oracle
     relative (5e-15 K(0) absolute in tol|k0|/2, below any NUFFT's accuracy) changes the ~12 000-panel schedule and
     moves the oracle's result by the same 2.4e-7 K(0), while its distance to the closed form stays 1.26e-7 K(0):
     in this regime (the algorithm stops short by ~1000 tol) every schedule is as good as any other."""
-    from seed27 import seed27_case
+    from stress_cases import seed27_case
     rs, k0, mk, truth = seed27_case(oracle)
     res = []
     for eps in (0.0, 1e-4):

@@ -1,3 +1,4 @@
+"""Panel schedules of the bench workloads under batch_panels = 1, 2, 4, 8 (what batching can and cannot save)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
