@@ -240,6 +240,9 @@ struct ReductionsB {
   unsigned int hi[kBatchMax][64];   // highest lag failing the convergence predicate of slot j, +1
   int nan[kBatchMax];               // per slot: bit 0 NaN in I1, bit 1 NaN in I2
   int pad[8];
+  // the VALUE of that lag (bit pattern of a positive double; the lags ascend, so the maximum over the workgroups is the
+  // lag with the highest index): the next panel's r_hi (src/adaptive.jl:152) without a dependent load in the transition
+  unsigned long long rhi_bits[kBatchMax][64];
 };
 
 // Pinned, host-mapped block through which k_advance reports the state (polled by the host).
