@@ -383,13 +383,12 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   // device-resident dim-1 march on a catalogue SDF: batched steps (sk_batch_kernels.inc)
   const bool batched = !host_step && cfg->dc.dim == 1 && !g_no_fuse;
   if (batched && cfg->k_adaptive) {
-    if (cfg->narrow && n == cfg->probe_n && cfg->narrow_calls < 63) {
-      cfg->dc.K = 1;
-      cfg->narrow_calls++;
-    } else {
-      cfg->dc.K = cfg->k_full;
-      cfg->narrow_calls = 0;
-    }
+    // Automatic batch width.  A config whose last full-width march never built a step of more than one panel runs the
+    // lighter one-panel instantiations; such a march gives the full width's bits (every step holds one panel either
+    // way), re-derives the full width's batching decisions as it goes (dc.Kv) and, should the input be one that WOULD
+    // batch, is repeated at the full width below -- the result is a function of the input, not of the call history.
+    cfg->dc.K = cfg->narrow ? 1 : cfg->k_full;
+    cfg->dc.Kv = cfg->narrow ? cfg->k_full : 0;
   }
   int R = (host_step || batched) ? 1 : 2;
   const int nu_main = cfg->dc.derivative ? cfg->dc.dim / 2 : cfg->dc.dim / 2 - 1;  // src/quadrature.jl:176-180
@@ -794,9 +793,19 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   stt.sum_active_steps = batched ? hs->sum_active_steps : hs->sum_active;
   stt.n_fix = batched ? hs->n_fix : 0;
   if (batched) cfg->last_n_steps = hs->n_steps + hs->n_rerun;
-  if (batched && cfg->k_adaptive && cfg->dc.K == cfg->k_full) {
-    cfg->narrow = hs->n_panels >= 2 && hs->n_steps >= hs->n_panels;
-    cfg->probe_n = n;
+  if (batched && cfg->k_adaptive && hs->done > 0) {
+    if (cfg->dc.K == cfg->k_full) {
+      cfg->narrow = hs->n_panels >= 2 && hs->n_multi == 0;
+    } else if (hs->would_batch) {
+      // this input batches at the full width: its result is the full-width march's (once; the config stays wide)
+      cfg->narrow = false;
+      const sk_stats keep = cfg->stats;
+      std::memset(&cfg->stats, 0, sizeof(cfg->stats));
+      cfg->stats.n_unique = keep.n_unique;
+      cfg->ev_recs.clear();
+      cfg->ev_used = 0;
+      return run_core(cfg, d_uxs, n, k0, ks0, d_ks, d_errs, d_scratch6n, st, false, nullptr);
+    }
   }
   cfg->trace_len = (size_t)hs->trace_len;
   cfg->trace_valid = false;

@@ -43,14 +43,12 @@ struct sk_config {
   rocfft_plan plan_b = nullptr;     // batched march: 4 K transforms of length n1 (bfft -> bfft_out)
   rocfft_execution_info info_b = nullptr;
   void* fft_work_b = nullptr;
-  // automatic batch_panels only: a config whose marches gain nothing from batching (every step one panel: each panel
-  // retires lags or is bisected) runs the K = 1 instantiations -- lighter kernels -- and re-probes with the full K every
-  // 64th call or when the number of lags changes
+  // automatic batch_panels only: a config whose last full-width march never built a step of more than one panel (each
+  // panel retires lags or is bisected on its own) runs the K = 1 instantiations -- lighter kernels, the same bits; the
+  // one-panel march notices an input that would batch (DevState::would_batch) and is then repeated at the full width
   int k_full = 0;                   // dc.K of the full batch
   bool k_adaptive = false;
-  bool narrow = false;              // the last full-K march saved no step
-  int narrow_calls = 0;
-  long long probe_n = -1;
+  bool narrow = false;              // the last full-width march built one-panel steps only
   rocfft_plan plan_b1 = nullptr;    // 4 transforms of length n1 (K = 1)
   rocfft_execution_info info_b1 = nullptr;
   void* fft_work_b1 = nullptr;

@@ -119,6 +119,8 @@ struct DevConst {
   const int4* tiles[2];
   int ntiles[2];
   int K;                        // batched march: most panels per step (1, 2, 4 or 8)
+  int Kv;                       // K = 1 chosen by the automatic batch width: the full width, whose batching decisions the
+                                // one-panel march re-derives to notice an input that would batch (0: no such check)
   int guess_mode;               // 0: runs extended on the certain criterion or the guess; 1: always extended
                                 // (SK_BATCH_GUESS=always: tests drive the re-run and output-fix paths); 2: certain only
 };
@@ -212,6 +214,9 @@ struct DevState {
   int spec_ok, fix_conf;        // the last completed outer panel retired nothing; buffer of the pending output fix
   long long fix_lo, fix_hi;     // lags [fix_lo, fix_hi) retired at slot 0 of a longer batch: outputs = sums in fix_conf
   TailScalars fix_tail;         //   + 2 x the truncation bound of that slot (src/adaptive.jl:194)
+  // automatic batch width (sk_api.cpp): n_multi = steps built with more than one slot (applied or not); would_batch: a
+  // one-panel march (K = 1 instantiation, dc.Kv > 1) reached a state at which the full width would have built one
+  int n_multi, would_batch;
   BatchInfo bt;
 };
 

@@ -176,23 +176,50 @@ def test_launch_floor_probe_is_safe_on_any_config_state(sk):
         assert np.array_equal(ks, ks2[:3]) or np.abs(ks - ks2[:3]).max() <= 1e-8
 
 
-@pytest.mark.parametrize("kind,prm,kw,mk", [
-    # every panel retires lags (the C3 pattern): the config switches to the one-panel kernels after its first march
-    ("matern", (2.14, 0.97, 0.89), dict(alpha=0.4, quadspec=(256, 16)), lambda: 10.0 ** np.linspace(-8, -2, 20000)),
-    # runs of outer panels (the C5 pattern): the full batch width stays
-    ("matern", (2.14, 0.97, 0.89), dict(tol=1e-12, quadspec=(256, 16)), lambda: np.linspace(0.0, 5.1, 20001)),
+def _full_width(kw):
+    m, k = kw.get("quadspec", (4096, 16))
+    return 2 if m * k > 40000 else 4  # sk_config_create: K n1 <= 2^17
+
+
+AUTO_INPUTS = [
+    # every panel retires lags (the C3 pattern): one-panel steps only -- the config switches to the K = 1 kernels
+    ("retiring", lambda: 10.0 ** np.linspace(-8, -2, 20000)),
+    # runs of outer panels (the C5 pattern): batches at the full width
+    ("runs", lambda: np.linspace(0.0, 5.1, 20001)),
+    ("retiring_short", lambda: 10.0 ** np.linspace(-7, -3, 5000)),
+]
+
+
+@pytest.mark.parametrize("kind,prm,kw", [
+    ("matern", (2.14, 0.97, 0.89), dict(alpha=0.4, quadspec=(256, 16))),
+    ("matern", (2.14, 0.97, 0.89), dict(tol=1e-12, quadspec=(256, 16))),
+    ("matern", (1.0, 1.0, 1.5), dict()),
 ])
-def test_automatic_batch_width_does_not_change_the_results(sk, kind, prm, kw, mk):
-    rs = mk()
+def test_automatic_batch_width_gives_results_that_depend_on_the_input_only(sk, kind, prm, kw):
+    """VERDICT r3 #6 / ADVICE r3: the reference's kernel_values is a pure function of its input (src/adaptive.jl:95-108).
+    With batch_panels = 0 a config may run the one-panel kernels after a march that never batched; whatever it ran
+    before, every call must return, bit for bit, what the full batch width returns on that input -- including the first
+    call, calls after an input of the other kind, and many repeated calls (the old rule re-probed every 64th)."""
+    K = _full_width(kw)
     auto = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), **kw)
-    one = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), batch_panels=1, **kw)
+    full = sk.AdaptiveKernelConfig(getattr(sk.SDF, kind)(*prm), batch_panels=K, **kw)
     k0 = sk.compute_k0(auto)
-    ref = sk.kernel_values(one, rs, k0=k0)
-    sched = _sched(one)
-    for call in range(4):  # the first call probes with the full width, the later ones run what it chose
-        k, e = sk.kernel_values(auto, rs, k0=k0)
-        assert _sched(auto) == sched, call
-        assert np.nanmax(np.abs(k - ref[0])) <= 2e-13 * abs(k0) and np.array_equal(np.isnan(e), np.isnan(ref[1])), call
-        if call:
-            assert np.array_equal(k, prev[0]) and np.array_equal(e, prev[1], equal_nan=True), call
-        prev = (k, e)
+    ref, sched, steps = {}, {}, {}
+    for name, mk in AUTO_INPUTS:
+        ref[name] = sk.kernel_values(full, mk(), k0=k0)
+        sched[name] = _sched(full)
+        steps[name] = full.last_stats()["n_steps"]
+    order = ["retiring", "retiring", "runs", "retiring", "retiring_short", "runs", "runs", "retiring"] + ["retiring"] * 70
+    seen_narrow = False
+    for call, name in enumerate(order):
+        k, e = sk.kernel_values(auto, dict(AUTO_INPUTS)[name](), k0=k0)
+        assert _sched(auto) == sched[name], (call, name)
+        assert np.array_equal(k, ref[name][0]), (call, name, np.nanmax(np.abs(k - ref[name][0])) / abs(k0))
+        assert np.array_equal(e, ref[name][1], equal_nan=True), (call, name)
+        st = auto.last_stats()
+        assert st["n_steps"] == steps[name], (call, name)
+        seen_narrow |= st["n_steps"] == st["n_panels"] and st["n_panels"] >= 2
+    if "alpha" in kw:  # the singular config: every panel of `retiring` retires lags -- marches the one-panel kernels can take
+        assert seen_narrow
+
+
