@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "sk_config.h"
 
@@ -968,6 +969,51 @@ int sort_unique_on_device(sk_config* cfg, const double* xs, size_t n, std::vecto
 
 }  // namespace sk
 
+// Independent marches at once: one host thread and the config's own stream per config.  A march in dim >= 2 is a chain of
+// small launches with a host round trip per step that leaves most of the device idle (step_frac 0.02 on BASELINE config
+// 4); the marches of the integrands of a Jacobian (src/derivatives.jl:51-112: one kernel_values call per integrand on the
+// same lags) share nothing but their input, so they overlap instead of queueing.  Catalogue SDFs only (a host closure is
+// called on the caller's thread, see sk_sdf_batch_fn), distinct configs; SK_MULTI_SERIAL=1 keeps the marches in sequence.
+static bool marches_can_overlap(sk_config* const* cfgs, size_t ncfg) {
+  if (ncfg < 2 || getenv("SK_MULTI_SERIAL") != nullptr) return false;
+  for (size_t c = 0; c < ncfg; ++c) {
+    if (cfgs[c]->args.sdf_kind == SK_SDF_CALLBACK) return false;
+    for (size_t d = 0; d < c; ++d)
+      if (cfgs[d] == cfgs[c]) return false;
+  }
+  return true;
+}
+// runs work(c) for every config, on threads of their own when the marches can overlap; first failure wins
+template <class Work>
+static int for_each_march(sk_config* const* cfgs, size_t ncfg, Work&& work) {
+  if (!marches_can_overlap(cfgs, ncfg)) {
+    for (size_t c = 0; c < ncfg; ++c) {
+      const int rc = work(c);
+      if (rc) return rc;
+    }
+    return SK_OK;
+  }
+  std::vector<int> rcs(ncfg, SK_OK);
+  std::vector<std::string> msgs(ncfg);
+  auto run = [&](size_t c) {
+    if (hipSetDevice(cfgs[c]->device) != hipSuccess) {
+      rcs[c] = SK_EHIP;
+      msgs[c] = "hipSetDevice failed";
+      return;
+    }
+    rcs[c] = work(c);
+    if (rcs[c]) msgs[c] = sk_last_error();  // the error channel is thread-local
+  };
+  std::vector<std::thread> th;
+  for (size_t c = 1; c < ncfg; ++c) th.emplace_back(run, c);
+  run(0);
+  for (auto& t : th) t.join();
+  for (size_t c = 0; c < ncfg; ++c)
+    if (rcs[c]) return fail(rcs[c], msgs[c]);
+  return SK_OK;
+}
+
+
 // ====================================================================== C ABI
 
 extern "C" {
@@ -1510,22 +1556,19 @@ int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs
   sk_config* c0 = cfgs[0];
   HIPCHK(hipSetDevice(c0->device));
   hipStream_t st = c0->own_stream;
-  // device buffers of this call (grow-only, owned by the first config): lags, sorted unique lags, inverse map,
-  // per-config unique results and gathered results (values and errors adjacent), sort scratch
+  // device buffers of this call (grow-only, owned by the first config): lags, sorted unique lags, inverse map, sort
+  // scratch; per config its unique results and its gathered results (values and errors adjacent)
   const size_t a8 = ((n * 8 + 255) / 256) * 256;
   const size_t tb = sort_unique_temp_bytes((long long)n);
-  int rc = ensure_dev(&c0->d_aux, &c0->aux_bytes, 7 * a8 + tb + 512);
+  int rc = ensure_dev(&c0->d_aux, &c0->aux_bytes, (3 + 4 * ncfg) * a8 + tb + 512);
   if (rc) return rc;
   char* buf = (char*)c0->d_aux;
   double* d_xs = (double*)buf;
   double* uxs = (double*)(buf + a8);
   long long* inv = (long long*)(buf + 2 * a8);
-  double* ks = (double*)(buf + 3 * a8);
-  double* errs = (double*)(buf + 4 * a8);
-  double* gk = (double*)(buf + 5 * a8);      // gathered values, then (n doubles later) gathered errors
-  double* ge = gk + n;
-  long long* d_nu = (long long*)(buf + 7 * a8);
-  void* tmp = buf + 7 * a8 + 256;
+  char* per = buf + 3 * a8;  // config c: ks, errs, then gathered values and (n doubles later) gathered errors
+  long long* d_nu = (long long*)(buf + (3 + 4 * ncfg) * a8);
+  void* tmp = (char*)d_nu + 256;
   int order = SK_ORDER_UNKNOWN;
   rc = h2d_doubles(c0, d_xs, xs, n, st, &order);
   if (rc) return rc;
@@ -1536,21 +1579,29 @@ int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs
   const bool sorted = (order == SK_ORDER_SORTED);
   if (!sorted) {
     if (sort_unique_sync(d_xs, (long long)n, uxs, inv, d_nu, c0->h_nuniq, tmp, tb, st, &nu)) return fail(SK_EHIP, "sort failed");
+  } else {
+    HIPCHK(hipStreamSynchronize(st));  // the marches below run on the configs' own streams
   }
-  for (size_t c = 0; c < ncfg; ++c) {
+  return for_each_march(cfgs, ncfg, [&](size_t c) -> int {
+    sk_config* cf = cfgs[c];
+    hipStream_t sc = cf->own_stream;
+    double* ks = (double*)(per + (4 * c) * a8);
+    double* errs = (double*)(per + (4 * c + 1) * a8);
+    double* gk = (double*)(per + (4 * c + 2) * a8);
+    double* ge = gk + n;
     const int pd = param_derivative ? param_derivative[c] : 0;
+    int r;
     if (sorted) {
-      rc = kernel_values_device_order(cfgs[c], d_xs, n, k0s[c], pd, gk, ge, st, SK_ORDER_SORTED);
+      r = kernel_values_device_order(cf, d_xs, n, k0s[c], pd, gk, ge, sc, SK_ORDER_SORTED);
     } else {
       // (sorted and unique by construction; the device check of the first march still catches invalid lags)
-      rc = kernel_values_device_order(cfgs[c], uxs, (size_t)nu, k0s[c], pd, ks, errs, st,
-                                      order == SK_ORDER_UNSORTED ? SK_ORDER_SORTED : SK_ORDER_UNKNOWN);
-      if (!rc) launch_gather(ks, errs, inv, (long long)n, gk, ge, st);
+      r = kernel_values_device_order(cf, uxs, (size_t)nu, k0s[c], pd, ks, errs, sc,
+                                     order == SK_ORDER_UNSORTED ? SK_ORDER_SORTED : SK_ORDER_UNKNOWN);
+      if (!r) launch_gather(ks, errs, inv, (long long)n, gk, ge, sc);
     }
-    if (!rc) rc = d2h_doubles2(c0, vals_out + c * n, errs_out + c * n, gk, n, st);
-    if (rc) return rc;
-  }
-  return SK_OK;
+    if (!r) r = d2h_doubles2(cf, vals_out + c * n, errs_out + c * n, gk, n, sc);
+    return r;
+  });
 }
 
 // grow-only buffer of 3 n doubles: lags, values, errors of the pair entries
@@ -1672,29 +1723,34 @@ int multi_device_core(sk_config* const* cfgs, size_t ncfg, const double* d_lags,
   hipStream_t st = c0->own_stream;
   const size_t a8 = ((n * 8 + 255) / 256) * 256;
   const size_t tb = sort_unique_temp_bytes((long long)n);
-  int rc = ensure_dev(&c0->d_aux, &c0->aux_bytes, (4 + 2 * ncfg) * a8 + tb + 512);
+  int rc = ensure_dev(&c0->d_aux, &c0->aux_bytes, (2 + 4 * ncfg) * a8 + tb + 512);
   if (rc) return rc;
   char* buf = (char*)c0->d_aux;
   double* uxs = (double*)buf;
   long long* inv = (long long*)(buf + a8);
-  double* ks = (double*)(buf + 2 * a8);
-  double* errs = (double*)(buf + 3 * a8);
-  double* outv = (double*)(buf + 4 * a8);
+  double* outv = (double*)(buf + 2 * a8);
   double* oute = outv + ncfg * n;
-  long long* d_nu = (long long*)(buf + (4 + 2 * ncfg) * a8);
+  char* per = buf + (2 + 2 * ncfg) * a8;  // config c: its unique values and error estimates
+  long long* d_nu = (long long*)(buf + (2 + 4 * ncfg) * a8);
   void* tmp = (char*)d_nu + 256;
   long long nu = 0;
   int was_unsorted = 1, bad_lags = 0;
   if (sort_unique_sync(d_lags, (long long)n, uxs, inv, d_nu, c0->h_nuniq, tmp, tb, st, &nu, &was_unsorted, &bad_lags))
     return fail(SK_EHIP, "sort failed");
   if (bad_lags) return fail(SK_EINVAL, "lags must be non-negative and finite");
-  for (size_t c = 0; c < ncfg; ++c) {
-    rc = kernel_values_device_order(cfgs[c], uxs, (size_t)nu, k0, param_derivative ? param_derivative[c] : 0, ks, errs, st,
-                                    SK_ORDER_SORTED);
-    if (rc) return rc;
-    launch_gather(ks, errs, inv, (long long)n, outv + c * n, oute + c * n, st);
-  }
-  HIPCHK(hipStreamSynchronize(st));
+  // one march per config, on the configs' own streams and side by side where they can (for_each_march)
+  rc = for_each_march(cfgs, ncfg, [&](size_t c) -> int {
+    hipStream_t sc = cfgs[c]->own_stream;
+    double* ks = (double*)(per + (2 * c) * a8);
+    double* errs = (double*)(per + (2 * c + 1) * a8);
+    int r = kernel_values_device_order(cfgs[c], uxs, (size_t)nu, k0, param_derivative ? param_derivative[c] : 0, ks, errs, sc,
+                                       SK_ORDER_SORTED);
+    if (r) return r;
+    launch_gather(ks, errs, inv, (long long)n, outv + c * n, oute + c * n, sc);
+    if (hipStreamSynchronize(sc) != hipSuccess) return fail(SK_EHIP, "stream synchronisation failed");
+    return SK_OK;
+  });
+  if (rc) return rc;
   *d_vals = outv;
   *d_errs = oute;
   return SK_OK;
