@@ -589,15 +589,26 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         // the boxes (a chain of small launches) run beside the spread and the FFT, which do not depend on them; the
         // per-kernel event timing (sk_profile_enable) keeps everything on one stream
         const bool beside = hin.has_far && !cfg->profile && !g_hk_serial;
-        if (beside) {  // both chains start at once: the spread is issued ahead of the (longer) chain of the boxes
+        const bool has_near = hin.Qn > 0, has_inner = hin.Q > 0;
+        if (beside) {
+          // three chains start at once: the spread (issued first) and the FFT on the march's stream, the near box -- all
+          // the far kernel waits for, and only a panel that starts below om0 has one -- and the longer chain of the
+          // inner box, which only the interpolation of the lags up to r_c waits for
           HIPCHK(hipEventRecord(cfg->fork_event, st));
           launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, hin.nt, st);
-          HIPCHK(hipStreamWaitEvent(cfg->side_stream, cfg->fork_event, 0));
-          launch_hk_boxes(cfg->dc, db, hin, cfg->side_stream);
-          HIPCHK(hipEventRecord(cfg->join_event, cfg->side_stream));
+          if (has_near) {
+            HIPCHK(hipStreamWaitEvent(cfg->side_stream2, cfg->fork_event, 0));
+            launch_hk_boxes(cfg->dc, db, hin, cfg->side_stream2, 1);
+            HIPCHK(hipEventRecord(cfg->join_event2, cfg->side_stream2));
+          }
+          if (has_inner) {
+            HIPCHK(hipStreamWaitEvent(cfg->side_stream, cfg->fork_event, 0));
+            launch_hk_boxes(cfg->dc, db, hin, cfg->side_stream, 2);
+            HIPCHK(hipEventRecord(cfg->join_event, cfg->side_stream));
+          }
         } else {
           EvScope e(cfg, st, SK_K_NEAR);
-          launch_hk_boxes(cfg->dc, db, hin, st);
+          launch_hk_boxes(cfg->dc, db, hin, st, 3);
         }
         if (hin.has_far) {
           if (!beside) { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, hin.nt, st); }
@@ -606,12 +617,15 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
             int rcf = run_fft_hk(cfg, hin.nt, st);
             if (rcf) return rcf;
           }
-          if (beside) HIPCHK(hipStreamWaitEvent(st, cfg->join_event, 0));
+          if (beside && has_near) HIPCHK(hipStreamWaitEvent(st, cfg->join_event2, 0));
           { EvScope e(cfg, st, SK_K_INTERP); launch_hk_far(cfg->dc, cfg->d_ec, db, hin, t & 1, n, raw, st); }
         }
         if (hin.lag_cnt > 0) {
+          if (beside && has_inner) HIPCHK(hipStreamWaitEvent(st, cfg->join_event, 0));
           EvScope e(cfg, st, SK_K_NEAR);
           launch_hk_iinterp(cfg->dc, db, hin, t & 1, n, raw, st);
+        } else if (beside && has_inner) {
+          HIPCHK(hipStreamWaitEvent(st, cfg->join_event, 0));  // (never alone in practice: an inner box has lags)
         }
         return SK_OK;
       }
@@ -1349,8 +1363,10 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
       db.hk_dct = (double*)p5;
     }
     if (hipStreamCreateWithFlags(&cfg->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&cfg->side_stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&cfg->fork_event, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&cfg->join_event, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&cfg->join_event, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&cfg->join_event2, hipEventDisableTiming) != hipSuccess) {
       sk_config_destroy(cfg);
       return fail(SK_EHIP, "hipStreamCreate (Hankel side stream) failed");
     }
@@ -1436,6 +1452,8 @@ void sk_config_destroy(sk_config* cfg) {
   if (cfg->own_stream) hipStreamDestroy(cfg->own_stream);
   if (cfg->copy_stream) hipStreamDestroy(cfg->copy_stream);
   if (cfg->side_stream) hipStreamDestroy(cfg->side_stream);
+  if (cfg->side_stream2) hipStreamDestroy(cfg->side_stream2);
+  if (cfg->join_event2) hipEventDestroy(cfg->join_event2);
   if (cfg->fork_event) hipEventDestroy(cfg->fork_event);
   if (cfg->join_event) hipEventDestroy(cfg->join_event);
   if (cfg->up_event) hipEventDestroy(cfg->up_event);

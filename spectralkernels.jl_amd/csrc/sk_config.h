@@ -114,8 +114,9 @@ struct sk_config {
   hipStream_t own_stream = nullptr;
   hipStream_t copy_stream = nullptr;  // bulk upload of the host-array entry, beside the first step (up_event)
   hipEvent_t up_event = nullptr;
-  hipStream_t side_stream = nullptr;  // Hankel path: the boxes run beside the NUFFT (fork / join events)
-  hipEvent_t fork_event = nullptr, join_event = nullptr;
+  hipStream_t side_stream = nullptr;  // Hankel path: the boxes run beside the NUFFT (fork / join events): inner box
+  hipStream_t side_stream2 = nullptr; //   ... and the near box, which is all the far kernel waits for
+  hipEvent_t fork_event = nullptr, join_event = nullptr, join_event2 = nullptr;
   // last call
   sk_stats stats;
   std::vector<TraceRec> trace;

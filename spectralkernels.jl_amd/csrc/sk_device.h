@@ -315,7 +315,7 @@ void launch_lw_finish(const DevConst& dc, const DevBuffers& db, int slot, long l
 // far sources (w >= om) of one level: all series terms spread in one launch
 void launch_hk_spread(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, double om, int nt, hipStream_t st);
 void launch_hk_near(const DevConst& dc, const DevBuffers& db, const HankelPlan& hp, hipStream_t st);
-void launch_hk_boxes(const DevConst& dc, const DevBuffers& db, const HkInner& hi, hipStream_t st);
+void launch_hk_boxes(const DevConst& dc, const DevBuffers& db, const HkInner& hi, hipStream_t st, int which = 3);  // bit 0 near, bit 1 inner
 void hk_series_fill(HkSeries& ser, const double* a, int nu);
 void launch_hk_far(const DevConst& dc, const EsConst* ec, const DevBuffers& db, const HkInner& hi, int slot, long long n, int raw,
                    hipStream_t st);

@@ -518,23 +518,64 @@ __global__ void k_tail(DevConst dc, DevBuffers db, int slot) {
 
 // Round boundary: materialises state_t for the host (pinned, host-mapped status block) without
 // launching the next step.
-__global__ void __launch_bounds__(64) k_advance(DevConst dc, DevBuffers db, int mode, int t, long long n, double k0,
-                                                 double ks0, unsigned int seq) {
+__global__ void __launch_bounds__(128) k_advance(DevConst dc, DevBuffers db, int mode, int t, long long n, double k0,
+                                                  double ks0, unsigned int seq) {
   __shared__ DevState sh;
   step_state(sh, dc, db, mode, t, n, k0, ks0, blockIdx.x == 0);
   // dim > 1, catalogue SDF: the tail fit of a new outer panel right here (the thread that published the state; program
   // order) instead of a k_tail launch behind the host round trip
   if (threadIdx.x == 0 && dc.dim > 1 && dc.sdf_kind != SK_SDF_CALLBACK && !sh.done) resolve_tail(db.state[t & 1], dc);
-  if (dc.dim > 1 && !sh.done && threadIdx.x <= kHkMaxLevels) {
-    // lags per level edge for the Hankel path's level planning: first active index with xs > r_hi / beta^l
-    double edge = sh.pp.r_hi;
-    for (int q = 0; q < (int)threadIdx.x; ++q) edge /= kHkBeta;
-    long long lo = sh.ix1, hi = sh.hi;  // xs[lo..hi) sorted ascending
-    while (lo < hi) {
-      const long long mid = (lo + hi) >> 1;
-      if (db.xs[mid] <= edge) lo = mid + 1; else hi = mid;
+  if (dc.dim > 1 && !sh.done && threadIdx.x >= 64) {  // the second wave, beside the first one's tail fit
+    // lags per level edge for the Hankel path's planning: for every l the first active index with xs > r_hi / beta^l.
+    // One 64-ary search for all levels at once: each round every lane probes one position per level (the loads of the
+    // 13 levels are independent and in flight together), a ballot narrows each bracket by a factor 64 -- four rounds
+    // for 10^6 lags where the lane-per-level bisection took twenty dependent loads (12 of k_advance's 14 us).
+    constexpr int NL = kHkMaxLevels + 1;
+    const int lane = (int)threadIdx.x - 64;
+    const long long ix1 = sh.ix1;
+    long long lo[NL], hi[NL];
+    double edge[NL];
+    {
+      double e = sh.pp.r_hi;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        edge[l] = e;
+        e /= kHkBeta;
+        lo[l] = ix1;
+        hi[l] = sh.hi;  // xs[lo..hi) sorted ascending; answer in [lo, hi]
+      }
     }
-    db.host_status->lvl_cnt[threadIdx.x] = lo - sh.ix1;
+    for (int round = 0; round < 8; ++round) {
+      bool any = false;
+      double v[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const long long len = hi[l] - lo[l];
+        v[l] = 0.0;
+        if (len > 0) {
+          any = true;
+          v[l] = db.xs[lo[l] + (len * lane) / 64];
+        }
+      }
+      if (!any) break;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const long long len = hi[l] - lo[l];
+        if (len > 0) {
+          // the probes ascend with the lane: `<= edge` holds on a prefix of c lanes; the answer lies behind probe c - 1
+          // and at or before probe c
+          const int c = __popcll(__ballot(v[l] <= edge[l]));
+          const long long nlo = c == 0 ? lo[l] : lo[l] + (len * (c - 1)) / 64 + 1;
+          const long long nhi = c == 64 ? hi[l] : lo[l] + (len * c) / 64;
+          lo[l] = nlo;
+          hi[l] = nhi < nlo ? nlo : nhi;
+        }
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) db.host_status->lvl_cnt[l] = lo[l] - ix1;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -2059,7 +2100,7 @@ void launch_tail(const DevConst& dc, const DevBuffers& db, int slot, hipStream_t
 }
 void launch_advance(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                     unsigned int seq, hipStream_t st) {
-  hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, dc, db, mode, t, n, k0, ks0, seq);
+  hipLaunchKernelGGL(k_advance, dim3(1), dim3(128), 0, st, dc, db, mode, t, n, k0, ks0, seq);
 }
 
 #ifdef SK_DEV_FAST  // development builds: two kernel widths only (compile time)

@@ -69,13 +69,13 @@ def test_hankel_and_sort_kernels_resources():
     # (<= 168 VGPRs: with the generic jn inlined it took all 256 -- one wave per SIMD, 200 us), the wave sort in registers
     ks = _kernels()
     hk = {k: v for k, v in ks.items() if "sk::k_hk_" in k or "sk::k_bk_" in k or "sk::k_spread_multi" in k}
-    assert sum("k_hk_far<" in k for k in hk) >= 7 and sum("k_hk_nodes<" in k for k in hk) == 3, sorted(hk)
+    assert sum("k_hk_far<" in k for k in hk) >= 7 and sum("k_hk_nodes<" in k for k in hk) == 6, sorted(hk)
     bad = {k: v for k, v in hk.items() if v["vgpr_spill"] > 0 or v["scratch"] > 0}
     assert not bad, "\n".join("%s %s" % kv for kv in sorted(bad.items()))
     far = [v for k, v in hk.items() if "k_hk_far<12>" in k]
     assert len(far) == 1 and far[0]["vgpr"] <= 128 and far[0]["lds"] <= 40960, far
     for nu in (0, 1):
-        nodes = [v for k, v in hk.items() if "k_hk_nodes<%d>" % nu in k]
-        assert len(nodes) == 1 and nodes[0]["vgpr"] <= 168 and nodes[0]["lds"] == 0, nodes
+        nodes = [v for k, v in hk.items() if "k_hk_nodes<%d, " % nu in k]  # near-box and inner-box instantiation
+        assert len(nodes) == 2 and all(v["vgpr"] <= 168 and v["lds"] == 0 for v in nodes), nodes
     wave = [v for k, v in hk.items() if "k_bk_sort_wave" in k]
     assert len(wave) == 1 and wave[0]["lds"] == 0 and wave[0]["vgpr"] <= 128, wave
