@@ -176,6 +176,9 @@ struct BatchInfo {
   // only one writes the stack, so the others must not read that entry back from memory in the same launch
   int push_valid;
   int tails_pending;   // the tail fits of this batch's slots are left to the end of the spread launch (off the critical path)
+  // sibling pair whose LEFT child starts at 0 with p != 0: slot 1's first sub-panel is Gauss-Jacobi (src/quadrature.jl:
+  // 61-78) -- its own source positions and tile list (variant 1) in the spread launch, everything behind the FFT alike
+  int mixed, pad_bt;
   double push_a, push_b;
   double Cx0, dCx;     // centre of slot 0, centre step per slot (-2X: siblings, +2X: outer run)
   double pa[kBatchMax], pb[kBatchMax];  // the reference's bounds of every slot (trace, bisection)

@@ -176,6 +176,34 @@ def test_launch_floor_probe_is_safe_on_any_config_state(sk):
         assert np.array_equal(ks, ks2[:3]) or np.abs(ks - ks2[:3]).max() <= 1e-8
 
 
+def test_sibling_pair_with_a_jacobi_left_child_is_one_step(sk, oracle):
+    """a singular SDF (p != 0) on the default rule bisects its first panel [0, b] repeatedly
+    (src/quadrature.jl:268-270); the left child of every such split starts at 0 -- Gauss-Jacobi first sub-panel
+    (:61-78), other source positions -- and used to be evaluated in a step of its own.  Now the pair (right child
+    Legendre, left child Jacobi) is one step with two tile lists: same schedule, same values, fewer steps."""
+    prm = (1.0, 1e-3, 1.5)  # a narrow SDF: the first panels are bisected down to its width
+    rs = 10.0 ** np.linspace(-4, 0, 600)
+    kw = dict(alpha=0.4, tol=1e-8, quadspec=(64, 4))
+    one = sk.AdaptiveKernelConfig(sk.SDF.matern(*prm), batch_panels=1, **kw)
+    two = sk.AdaptiveKernelConfig(sk.SDF.matern(*prm), batch_panels=2, **kw)
+    k0 = sk.compute_k0(one)
+    k1, e1 = sk.kernel_values(one, rs, k0=k0)
+    k2, e2 = sk.kernel_values(two, rs, k0=k0)
+    assert _sched(one) == _sched(two)
+    tr = one.last_trace()
+    splits_at_zero = sum(1 for r in tr if r["a"] == 0.0 and not r["accepted"])
+    assert splits_at_zero >= 3, tr[:6]
+    s1, s2 = one.last_stats(), two.last_stats()
+    assert s1["n_steps"] == s1["n_panels"] and s2["n_panels"] == s1["n_panels"]
+    # every split of a panel that starts at 0 leaves such a pair behind: at least that many steps saved
+    assert s2["n_steps"] <= s1["n_panels"] - splits_at_zero, (s1, s2, splits_at_zero)
+    assert np.nanmax(np.abs(k2 - k1)) <= 2e-13 * abs(k0) and np.array_equal(np.isnan(e1), np.isnan(e2))
+    # and against the oracle (direct sums, same rule): same schedule, values to a tenth of the tolerance
+    ocfg = oracle.AdaptiveKernelConfig(oracle.SDF.matern(*prm), alpha=0.4, tol=1e-8, quadspec=(64, 4))
+    ok, _ = oracle.kernel_values(ocfg, rs, k0=k0)
+    assert np.abs(k2 - ok).max() <= 1e-9 * abs(k0)
+
+
 def _full_width(kw):
     m, k = kw.get("quadspec", (4096, 16))
     return 2 if m * k > 40000 else 4  # sk_config_create: K n1 <= 2^17
