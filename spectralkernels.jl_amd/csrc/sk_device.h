@@ -7,6 +7,11 @@ namespace sk {
 
 constexpr int kMaxWidth = 16;
 constexpr int kMaxNco = kMaxWidth / 2 + 1;
+// Coefficients per half (even / odd part) of the ES kernel's piecewise polynomials: degree 2 nco - 1.  The approximation
+// error bottoms out at the kernel's own cutoff jump e^-beta once the degree reaches w - 1 (w = 12: 1.6e-12 at degree 11
+// and at 13; 5e-11 at 9) -- one coefficient per half less than rounds 1-3 carried, 13 FP64 instructions per lag and per
+// staged source less; the narrow kernels (w <= 8, tol >= 1e-4) keep degree w + 1, where the last coefficient still buys 2.5x.
+__host__ __device__ constexpr int es_nco(int w) { return w >= 10 ? w / 2 : w / 2 + 1; }
 constexpr int kMaxCheb = 24;
 constexpr int kStackCap = 5000;  // src/quadrature.jl:7
 constexpr int kTraceCap = 4096;

@@ -616,7 +616,7 @@ __device__ __forceinline__ void lds_dma16(const double2* src, double2* lds_wave_
 // 200 of k_interp's 590 VALU instructions per wave, found with SQ_INSTS_VALU / the ISA histogram).
 template <int W, class TablePtr>
 __device__ __forceinline__ void es_weights(TablePtr poly, double y, double (&wt)[W]) {
-  constexpr int NCO = W / 2 + 1;
+  constexpr int NCO = es_nco(W);
   const double y2 = y * y;
   double pw[NCO];  // pw[i] = y2^i
   pw[0] = 1.0;
@@ -646,7 +646,7 @@ __device__ __forceinline__ void es_weights(TablePtr poly, double y, double (&wt)
 template <int W>
 __device__ __forceinline__ void stage_es_tables(const EsConst* __restrict__ ecp, double* s_poly, double* s_cheb) {
   const EsConst& ec = *ecp;
-  constexpr int NP = (W / 2) * 2 * (W / 2 + 1);
+  constexpr int NP = (W / 2) * 2 * es_nco(W);
   const double* gp = ec.poly;
   const double* gc = ec.cheb;
   for (int t = threadIdx.x; t < NP; t += blockDim.x) s_poly[t] = gp[t];
@@ -2234,7 +2234,7 @@ template <int W>
 __global__ void __launch_bounds__(256) k_seam_interp(DevConst dc, const EsConst* ec, const double2* fft, const double* xs, int64_t n,
                                                       double Cx, double r_hi, double tau, double theta_scale,
                                                       double* out_re, double* out_im) {
-  __shared__ double s_poly[(W / 2) * 2 * (W / 2 + 1)];
+  __shared__ double s_poly[(W / 2) * 2 * es_nco(W)];
   __shared__ double s_cheb[16];
   stage_es_tables<W>(ec, s_poly, s_cheb);
   __syncthreads();

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <vector>
 #include "sk_internal.h"
+#include "sk_device.h"
 
 namespace sk {
 typedef long double ld;
@@ -57,8 +58,8 @@ void build_es_tables(int w, int64_t n1, int64_t n2, double theta_max, EsTables& 
   else if (w == 3) t.beta = 2.26 * w;
   else if (w == 4) t.beta = 2.38 * w;
   const ld beta = t.beta;
-  // ---- piecewise polynomials, degree 2*nco-1 >= w+1
-  const int nco = w / 2 + 1;  // degree w+1: at the kernel's own cutoff accuracy exp(-beta)
+  // ---- piecewise polynomials, degree 2*nco-1 (es_nco, sk_device.h: at the kernel's own cutoff accuracy exp(-beta))
+  const int nco = es_nco(w);
   const int deg = 2 * nco - 1;
   t.nco = nco;
   t.poly.assign((size_t)(w / 2) * 2 * nco, 0.0);
