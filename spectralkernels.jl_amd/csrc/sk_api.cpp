@@ -384,10 +384,11 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   // device-resident dim-1 march on a catalogue SDF: batched steps (sk_batch_kernels.inc)
   const bool batched = !host_step && cfg->dc.dim == 1 && !g_no_fuse;
   if (batched && cfg->k_adaptive) {
-    // Automatic batch width.  A config whose last full-width march never built a step of more than one panel runs the
-    // lighter one-panel instantiations; such a march gives the full width's bits (every step holds one panel either
-    // way), re-derives the full width's batching decisions as it goes (dc.Kv) and, should the input be one that WOULD
-    // batch, is repeated at the full width below -- the result is a function of the input, not of the call history.
+    // Automatic batch width.  A config whose last full-width march never met a step at which panels could be batched
+    // (every panel a fresh outer panel of a march that is retiring lags: BASELINE config 3) runs the lighter one-panel
+    // instantiations; such a march gives the full width's bits (every step holds one panel either way), reports a step
+    // at which the full width COULD batch (dc.Kv, DevState::would_batch) and is then repeated at the full width below --
+    // the result is a function of the input, not of the call history.
     cfg->dc.K = cfg->narrow ? 1 : cfg->k_full;
     cfg->dc.Kv = cfg->narrow ? cfg->k_full : 0;
   }

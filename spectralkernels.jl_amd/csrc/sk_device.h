@@ -11,7 +11,11 @@ constexpr int kMaxNco = kMaxWidth / 2 + 1;
 // error bottoms out at the kernel's own cutoff jump e^-beta once the degree reaches w - 1 (w = 12: 1.6e-12 at degree 11
 // and at 13; 5e-11 at 9) -- one coefficient per half less than rounds 1-3 carried, 13 FP64 instructions per lag and per
 // staged source less; the narrow kernels (w <= 8, tol >= 1e-4) keep degree w + 1, where the last coefficient still buys 2.5x.
+#ifdef SK_OLD_NCO  // diagnostic builds: rounds 1-3's degree w + 1 everywhere (same-box A/B)
+__host__ __device__ constexpr int es_nco(int w) { return w / 2 + 1; }
+#else
 __host__ __device__ constexpr int es_nco(int w) { return w >= 10 ? w / 2 : w / 2 + 1; }
+#endif
 constexpr int kMaxCheb = 24;
 constexpr int kStackCap = 5000;  // src/quadrature.jl:7
 constexpr int kTraceCap = 4096;
@@ -125,7 +129,7 @@ struct DevConst {
   int ntiles[2];
   int K;                        // batched march: most panels per step (1, 2, 4 or 8)
   int Kv;                       // K = 1 chosen by the automatic batch width: the full width, whose batching decisions the
-                                // one-panel march re-derives to notice an input that would batch (0: no such check)
+                                // one-panel march re-derives (after its tiles) to notice an input that would batch; 0: no check
   int guess_mode;               // 0: runs extended on the certain criterion or the guess; 1: always extended
                                 // (SK_BATCH_GUESS=always: tests drive the re-run and output-fix paths); 2: certain only
 };
@@ -183,7 +187,9 @@ struct BatchInfo {
   int tails_pending;   // the tail fits of this batch's slots are left to the end of the spread launch (off the critical path)
   // sibling pair whose LEFT child starts at 0 with p != 0: slot 1's first sub-panel is Gauss-Jacobi (src/quadrature.jl:
   // 61-78) -- its own source positions and tile list (variant 1) in the spread launch, everything behind the FFT alike
-  int mixed, pad_bt;
+  int mixed;
+  int probe;           // one-panel march under the automatic batch width: the full width could batch at this step -- its
+                       // decision is re-derived after the tiles (batch_probe_full), off the critical path
   double push_a, push_b;
   double Cx0, dCx;     // centre of slot 0, centre step per slot (-2X: siblings, +2X: outer run)
   double pa[kBatchMax], pb[kBatchMax];  // the reference's bounds of every slot (trace, bisection)

@@ -12,8 +12,12 @@ for v in other new other new; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/tools/diag/devsteps.py $WL 200 > $d.log 2>&1 || exit 1
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   python3 - "$f" $v <<'PY'
-import csv, sys
-rows = {r["Name"][:24]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(sys.argv[1]))}
-print(sys.argv[2], {k: round(v, 2) for k, v in rows.items() if "sk::k_" in k and "warmup" not in k})
+import csv, re, sys
+rows = {}
+for r in csv.DictReader(open(sys.argv[1])):
+    if "sk::k_" in r["Name"] and "warmup" not in r["Name"] and int(r["Calls"]) >= 20:
+        name = re.sub(r"^void ", "", r["Name"]).split("(")[0]  # full instantiation name: <W, K, waves> differ in cost
+        rows[name] = "%.2f x%s" % (float(r["AverageNs"]) / 1e3, r["Calls"])
+print(sys.argv[2], rows)
 PY
 done
