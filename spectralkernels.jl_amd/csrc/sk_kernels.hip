@@ -2157,6 +2157,8 @@ void launch_hk_far(const DevConst& dc, const EsConst* ec, const DevBuffers& db, 
   // grid: the lags above r_c; the kernel leaves where its block starts beyond the active set
   const long long cnt = n - (hi.lag_lo + hi.lag_cnt);
   if (cnt <= 0) return;
+  // (two lags per lane sharing their tap reads -- 13 LDS reads for two lags instead of 24 -- was built and measured in
+  // round 4: 237 VGPRs, two waves per SIMD, 135 us against 84: the kernel needs its occupancy more than the reads)
   SK_DISPATCH_W(dc.w, hipLaunchKernelGGL(k_hk_far<W>, dim3(nblk(cnt, 256)), dim3(256), 0, st, dc, ec, db, hi, slot, n, raw));
 }
 void launch_hk_iinterp(const DevConst& dc, const DevBuffers& db, const HkInner& hi, int slot, long long n, int raw, hipStream_t st) {
