@@ -338,6 +338,178 @@ static int wait_status(sk_config* cfg, unsigned int seq, hipStream_t st) {
 int joint_wait_status(sk_config* cfg, unsigned int seq, hipStream_t st) { return wait_status(cfg, seq, st); }
 void joint_host_nodes(const sk_config* cfg, const PanelParams& pp, std::vector<double>& w) { host_nodes(cfg, pp, w); }
 
+// One step of the Hankel path by boxes (sk_hankel_inner.inc) for Bessel order nu (a_nu: its asymptotic coefficients) at
+// the state the device published in `hs`: one NUFFT triple for the lags above r_c = r_hi / 8^l, a directly summed near box
+// for the few sources below om0 there, the inner box (all sources, lags up to r_c) by moments.  l from a cost model in
+// Bessel evaluations; the lag counts per power of 8 come from k_advance.  boxes = false: the step does not fit the
+// buffers (the caller falls back to the level split).  Shared by the single-integrand march (run_core) and the joint
+// march of sk_joint.cpp.
+int hk_plan_boxes(sk_config* cfg, DevBuffers& db, const DevState* hs, int nu, const double* a_nu, int raw, hipStream_t st,
+                  HkInner& hin, bool& boxes) {
+  const double r_hi = hs->pp.r_hi, pb = hs->pp.pb;
+  int L = 0;
+  while (L < kHkMaxLevels - 1 && kHkZ0 * std::pow(kHkBeta, L + 1) / (2.0 * M_PI * r_hi) < pb) ++L;
+  std::memset(&hin, 0, sizeof(hin));
+  boxes = false;
+  if (cfg->hk_nb > 0) {
+    auto n_of_z = [](double z) { return std::ceil(z + 9.0 * std::cbrt(z) + 14.0); };
+    // series terms: the default count is sized for z0 = 24 (hk_terms); from a larger first z, the fewest terms with
+    // the same first omitted term
+    const int nt_full = hk_terms(cfg->dc.w);
+    double ak[kHkTerms + 2];
+    ak[0] = 1.0;
+    for (int q = 1; q <= kHkTerms + 1; ++q) ak[q] = ak[q - 1] * (4.0 * nu * nu - (2.0 * q - 1.0) * (2.0 * q - 1.0)) / (8.0 * q);
+    const double thr = std::fabs(ak[nt_full]) / std::pow(kHkZ0, nt_full);
+    auto terms_for = [&](double z) {
+      for (int K = 2; K < nt_full; ++K)
+        if (std::fabs(ak[K]) / std::pow(z, K) <= thr) return K;
+      return nt_full;
+    };
+    const double pa = hs->pp.pa;
+    const long long nact = hs->hi - hs->ix1;
+    hin.nu = nu;
+    hk_series_fill(hin.ser, a_nu, nu);
+    hin.pa = pa;
+    hin.pb = pb;
+    hin.r_hi = r_hi;
+    hin.lag_lo = hs->ix1;
+    hin.escale = (raw == SK_RAW_NONE && cfg->dc.dim > 2) ? cfg->dc.dim * 0.5 - 1.0 : 0.0;
+    // bands of the inner box for a given r_c: the fewest (divisors of k) with at most ~400 moments each
+    auto bands_for = [&](double r_c, int& nb, int& ngm) {
+      nb = 0;
+      for (int d = 1; d <= (int)cfg->k; ++d) {
+        if (cfg->k % d) continue;
+        const int ng = (int)n_of_z(M_PI * (pb - pa) / d * r_c) + 2;
+        if (ng > cfg->hk_ngmax) continue;
+        nb = d;
+        ngm = ng;
+        if (ng <= 400) break;
+      }
+      return nb > 0;
+    };
+    if (L == 0) {  // no far field: the whole panel is one smooth box
+      int nb, ngm;
+      const double qd = std::ceil(M_PI * pb * r_hi / 96.0);
+      if (bands_for(r_hi, nb, ngm) && qd <= (double)kHkQCap) {
+        hin.has_far = 0; hin.r_c = r_hi; hin.nb = nb; hin.ngm = ngm;
+        hin.Q = qd < 1.0 ? 1 : (int)qd;
+        hin.lag_cnt = nact;
+        boxes = true;
+      }
+    } else {
+      double best = INFINITY;
+      for (int l = 1; l < kHkMaxLevels; ++l) {
+        const double beta = std::pow(kHkBeta, l), r_c = r_hi / beta;
+        double om0 = kHkZ0 * beta / (2.0 * M_PI * r_hi);
+        if (om0 >= pb) break;  // nothing left for the series
+        const long long icnt = cfg->h_status->lvl_cnt[l];
+        // a panel that starts beyond om0 has no near sources; the series then runs from z >= 2 pi pa r_c > z0 on and
+        // needs fewer terms for the same truncation error
+        int nt = nt_full;
+        if (om0 <= pa) {
+          om0 = pa;
+          nt = terms_for(2.0 * M_PI * pa * r_c);
+        }
+        const double fnear = om0 <= pa ? 0.0 : (om0 - pa) / (pb - pa);
+        const double qn = fnear > 0.0 ? std::ceil(M_PI * om0 * (r_hi - r_c) / 96.0) : 0.0;
+        double cost = 3.0 * (double)cfg->M * fnear * qn * kHkNodes;
+        // spread + FFT: 8.6 us per term at 196 608 sources; taps: 7.4 us per term and 1e6 lags; 1 us ~ 7e4 evaluations
+        cost += nt * (3.06 * 3.0 * (double)cfg->M + 0.52 * (double)(nact - icnt));
+        int nb = 1, ngm = 0;
+        double qi = 0.0;
+        if (icnt > 0) {
+          if (!bands_for(r_c, nb, ngm)) continue;
+          qi = std::max(1.0, std::ceil(M_PI * pb * r_c / 96.0));
+          const double zb = M_PI * (pb - pa) / nb * r_c;
+          cost += qi * kHkNodes * nb * n_of_z(0.5 * zb) + 3.0 * (double)cfg->M * ngm / 22.0 + qi * 2.0 * nb * ngm * ngm / 110.0;
+        }
+        if (qn + qi > (double)kHkQCap) continue;
+        if (cost < best) {
+          best = cost;
+          hin.has_far = 1; hin.r_c = r_c; hin.om0 = om0; hin.nb = nb; hin.ngm = ngm; hin.nt = nt;
+          hin.Qn = (int)qn; hin.Q = (int)qi;
+          hin.lag_cnt = icnt;
+          boxes = true;
+        }
+      }
+    }
+    if (boxes) {
+      hin.gs = (int)cfg->k / hin.nb;
+      hin.ell = hin.Q > 0 ? hin.r_c / (double)hin.Q : hin.r_c;
+      hin.elln = hin.Qn > 0 ? (r_hi - hin.r_c) / (double)hin.Qn : r_hi;
+      const int qtot = hin.Q + hin.Qn;
+      // interval buffers (grow only; rare: the counts grow with the panel index): equivalent sources of the inner
+      // box, node values and Chebyshev coefficients of both boxes
+      const size_t wb = ((sizeof(double2) * (size_t)hin.Q * 2 * hin.nb * hin.ngm + 255) / 256) * 256;
+      const size_t vb = ((sizeof(double) * (size_t)qtot * 2 * kHkNodes + 255) / 256) * 256;
+      if (wb + 2 * vb > cfg->hk_qbytes) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (cfg->hk_qbuf) HIPCHK(hipFree(cfg->hk_qbuf));
+        cfg->hk_qbuf = nullptr;
+        cfg->hk_qbytes = 0;
+        const size_t want = (wb + 2 * vb) + (wb + 2 * vb) / 2 + (1u << 20);
+        HIPCHK(hipMalloc(&cfg->hk_qbuf, want));
+        cfg->hk_qbytes = want;
+      }
+      db.hk_w = (double2*)cfg->hk_qbuf;
+      db.hk_v = (double*)((char*)cfg->hk_qbuf + wb);
+      db.hk_c2 = (double*)((char*)cfg->hk_qbuf + wb + vb);
+    }
+  }
+  if (boxes && g_debug_hk)
+    fprintf(stderr, "[sk] hankel step: panel [%.6g, %.6g] r_hi %.6g  far %d r_c %.4g om0 %.5g nt %d  Qn %d  inner: lags %lld Q %d nb %d ngm %d\n",
+            hin.pa, hin.pb, hin.r_hi, hin.has_far, hin.r_c, hin.om0, hin.nt, hin.Qn, hin.lag_cnt, hin.Q, hin.nb, hin.ngm);
+  return SK_OK;
+}
+
+// The launches of one planned step: spread / FFT / far kernel on `st`, the two boxes beside them on the config's side
+// streams (the far kernel waits for the near box only), then the interpolation of the lags up to r_c.  raw != 0: the
+// evaluation kernels store the panel sums (db.lw_raw) instead of running the epilogue.
+int hk_launch_boxes(sk_config* cfg, DevBuffers& db, const HkInner& hin, int t, long long n, int raw, hipStream_t st) {
+  // the boxes (a chain of small launches) run beside the spread and the FFT, which do not depend on them; the
+  // per-kernel event timing (sk_profile_enable) keeps everything on one stream
+  const bool beside = hin.has_far && !cfg->profile && !g_hk_serial;
+  const bool has_near = hin.Qn > 0, has_inner = hin.Q > 0;
+  if (beside) {
+    // three chains start at once: the spread (issued first) and the FFT on the march's stream, the near box -- all
+    // the far kernel waits for, and only a panel that starts below om0 has one -- and the longer chain of the
+    // inner box, which only the interpolation of the lags up to r_c waits for
+    HIPCHK(hipEventRecord(cfg->fork_event, st));
+    launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, hin.nt, st);
+    if (has_near) {
+      HIPCHK(hipStreamWaitEvent(cfg->side_stream2, cfg->fork_event, 0));
+      launch_hk_boxes(cfg->dc, db, hin, cfg->side_stream2, 1);
+      HIPCHK(hipEventRecord(cfg->join_event2, cfg->side_stream2));
+    }
+    if (has_inner) {
+      HIPCHK(hipStreamWaitEvent(cfg->side_stream, cfg->fork_event, 0));
+      launch_hk_boxes(cfg->dc, db, hin, cfg->side_stream, 2);
+      HIPCHK(hipEventRecord(cfg->join_event, cfg->side_stream));
+    }
+  } else {
+    EvScope e(cfg, st, SK_K_NEAR);
+    launch_hk_boxes(cfg->dc, db, hin, st, 3);
+  }
+  if (hin.has_far) {
+    if (!beside) { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, hin.nt, st); }
+    {
+      EvScope e(cfg, st, SK_K_FFT);
+      int rcf = run_fft_hk(cfg, hin.nt, st);
+      if (rcf) return rcf;
+    }
+    if (beside && has_near) HIPCHK(hipStreamWaitEvent(st, cfg->join_event2, 0));
+    { EvScope e(cfg, st, SK_K_INTERP); launch_hk_far(cfg->dc, cfg->d_ec, db, hin, t & 1, n, raw, st); }
+  }
+  if (hin.lag_cnt > 0) {
+    if (beside && has_inner) HIPCHK(hipStreamWaitEvent(st, cfg->join_event, 0));
+    EvScope e(cfg, st, SK_K_NEAR);
+    launch_hk_iinterp(cfg->dc, db, hin, t & 1, n, raw, st);
+  } else if (beside && has_inner) {
+    HIPCHK(hipStreamWaitEvent(st, cfg->join_event, 0));  // (never alone in practice: an inner box has lags)
+  }
+  return SK_OK;
+}
+
 // core march on sorted unique lags already on the device (src/adaptive.jl:110-202)
 static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0, double ks0, double* d_ks, double* d_errs,
                     double* d_scratch6n /* 10 n for logw */, hipStream_t st, bool check_flags,
@@ -476,160 +648,12 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       // a cost model in Bessel evaluations; the lag counts per power of 8 come from k_advance.  Falls back to the level
       // split when a step does not fit the buffers.
       HkInner hin;
-      std::memset(&hin, 0, sizeof(hin));
       bool boxes = false;
-      if (cfg->hk_nb > 0) {
-        auto n_of_z = [](double z) { return std::ceil(z + 9.0 * std::cbrt(z) + 14.0); };
-        // series terms: the default count is sized for z0 = 24 (hk_terms); from a larger first z, the fewest terms with
-        // the same first omitted term
-        const int nt_full = hk_terms(cfg->dc.w);
-        double ak[kHkTerms + 2];
-        ak[0] = 1.0;
-        for (int q = 1; q <= kHkTerms + 1; ++q) ak[q] = ak[q - 1] * (4.0 * nu * nu - (2.0 * q - 1.0) * (2.0 * q - 1.0)) / (8.0 * q);
-        const double thr = std::fabs(ak[nt_full]) / std::pow(kHkZ0, nt_full);
-        auto terms_for = [&](double z) {
-          for (int K = 2; K < nt_full; ++K)
-            if (std::fabs(ak[K]) / std::pow(z, K) <= thr) return K;
-          return nt_full;
-        };
-        const double pa = hs->pp.pa;
-        const long long nact = hs->hi - hs->ix1;
-        hin.nu = nu;
-        hk_series_fill(hin.ser, hp.a, nu);
-        hin.pa = pa;
-        hin.pb = pb;
-        hin.r_hi = r_hi;
-        hin.lag_lo = hs->ix1;
-        hin.escale = (raw == SK_RAW_NONE && cfg->dc.dim > 2) ? cfg->dc.dim * 0.5 - 1.0 : 0.0;
-        // bands of the inner box for a given r_c: the fewest (divisors of k) with at most ~400 moments each
-        auto bands_for = [&](double r_c, int& nb, int& ngm) {
-          nb = 0;
-          for (int d = 1; d <= (int)cfg->k; ++d) {
-            if (cfg->k % d) continue;
-            const int ng = (int)n_of_z(M_PI * (pb - pa) / d * r_c) + 2;
-            if (ng > cfg->hk_ngmax) continue;
-            nb = d;
-            ngm = ng;
-            if (ng <= 400) break;
-          }
-          return nb > 0;
-        };
-        if (L == 0) {  // no far field: the whole panel is one smooth box
-          int nb, ngm;
-          const double qd = std::ceil(M_PI * pb * r_hi / 96.0);
-          if (bands_for(r_hi, nb, ngm) && qd <= (double)kHkQCap) {
-            hin.has_far = 0; hin.r_c = r_hi; hin.nb = nb; hin.ngm = ngm;
-            hin.Q = qd < 1.0 ? 1 : (int)qd;
-            hin.lag_cnt = nact;
-            boxes = true;
-          }
-        } else {
-          double best = INFINITY;
-          for (int l = 1; l < kHkMaxLevels; ++l) {
-            const double beta = std::pow(kHkBeta, l), r_c = r_hi / beta;
-            double om0 = kHkZ0 * beta / (2.0 * M_PI * r_hi);
-            if (om0 >= pb) break;  // nothing left for the series
-            const long long icnt = cfg->h_status->lvl_cnt[l];
-            // a panel that starts beyond om0 has no near sources; the series then runs from z >= 2 pi pa r_c > z0 on and
-            // needs fewer terms for the same truncation error
-            int nt = nt_full;
-            if (om0 <= pa) {
-              om0 = pa;
-              nt = terms_for(2.0 * M_PI * pa * r_c);
-            }
-            const double fnear = om0 <= pa ? 0.0 : (om0 - pa) / (pb - pa);
-            const double qn = fnear > 0.0 ? std::ceil(M_PI * om0 * (r_hi - r_c) / 96.0) : 0.0;
-            double cost = 3.0 * (double)cfg->M * fnear * qn * kHkNodes;
-            // spread + FFT: 8.6 us per term at 196 608 sources; taps: 7.4 us per term and 1e6 lags; 1 us ~ 7e4 evaluations
-            cost += nt * (3.06 * 3.0 * (double)cfg->M + 0.52 * (double)(nact - icnt));
-            int nb = 1, ngm = 0;
-            double qi = 0.0;
-            if (icnt > 0) {
-              if (!bands_for(r_c, nb, ngm)) continue;
-              qi = std::max(1.0, std::ceil(M_PI * pb * r_c / 96.0));
-              const double zb = M_PI * (pb - pa) / nb * r_c;
-              cost += qi * kHkNodes * nb * n_of_z(0.5 * zb) + 3.0 * (double)cfg->M * ngm / 22.0 + qi * 2.0 * nb * ngm * ngm / 110.0;
-            }
-            if (qn + qi > (double)kHkQCap) continue;
-            if (cost < best) {
-              best = cost;
-              hin.has_far = 1; hin.r_c = r_c; hin.om0 = om0; hin.nb = nb; hin.ngm = ngm; hin.nt = nt;
-              hin.Qn = (int)qn; hin.Q = (int)qi;
-              hin.lag_cnt = icnt;
-              boxes = true;
-            }
-          }
-        }
-        if (boxes) {
-          hin.gs = (int)cfg->k / hin.nb;
-          hin.ell = hin.Q > 0 ? hin.r_c / (double)hin.Q : hin.r_c;
-          hin.elln = hin.Qn > 0 ? (r_hi - hin.r_c) / (double)hin.Qn : r_hi;
-          const int qtot = hin.Q + hin.Qn;
-          // interval buffers (grow only; rare: the counts grow with the panel index): equivalent sources of the inner
-          // box, node values and Chebyshev coefficients of both boxes
-          const size_t wb = ((sizeof(double2) * (size_t)hin.Q * 2 * hin.nb * hin.ngm + 255) / 256) * 256;
-          const size_t vb = ((sizeof(double) * (size_t)qtot * 2 * kHkNodes + 255) / 256) * 256;
-          if (wb + 2 * vb > cfg->hk_qbytes) {
-            HIPCHK(hipStreamSynchronize(st));
-            if (cfg->hk_qbuf) HIPCHK(hipFree(cfg->hk_qbuf));
-            cfg->hk_qbuf = nullptr;
-            cfg->hk_qbytes = 0;
-            const size_t want = (wb + 2 * vb) + (wb + 2 * vb) / 2 + (1u << 20);
-            HIPCHK(hipMalloc(&cfg->hk_qbuf, want));
-            cfg->hk_qbytes = want;
-          }
-          db.hk_w = (double2*)cfg->hk_qbuf;
-          db.hk_v = (double*)((char*)cfg->hk_qbuf + wb);
-          db.hk_c2 = (double*)((char*)cfg->hk_qbuf + wb + vb);
-        }
+      {
+        int rcp = hk_plan_boxes(cfg, db, hs, nu, hp.a, raw, st, hin, boxes);
+        if (rcp) return rcp;
       }
-      if (boxes && g_debug_hk)
-        fprintf(stderr, "[sk] hankel step: panel [%.6g, %.6g] r_hi %.6g  far %d r_c %.4g om0 %.5g nt %d  Qn %d  inner: lags %lld Q %d nb %d ngm %d\n",
-                hin.pa, hin.pb, hin.r_hi, hin.has_far, hin.r_c, hin.om0, hin.nt, hin.Qn, hin.lag_cnt, hin.Q, hin.nb, hin.ngm);
-      if (boxes) {
-        // the boxes (a chain of small launches) run beside the spread and the FFT, which do not depend on them; the
-        // per-kernel event timing (sk_profile_enable) keeps everything on one stream
-        const bool beside = hin.has_far && !cfg->profile && !g_hk_serial;
-        const bool has_near = hin.Qn > 0, has_inner = hin.Q > 0;
-        if (beside) {
-          // three chains start at once: the spread (issued first) and the FFT on the march's stream, the near box -- all
-          // the far kernel waits for, and only a panel that starts below om0 has one -- and the longer chain of the
-          // inner box, which only the interpolation of the lags up to r_c waits for
-          HIPCHK(hipEventRecord(cfg->fork_event, st));
-          launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, hin.nt, st);
-          if (has_near) {
-            HIPCHK(hipStreamWaitEvent(cfg->side_stream2, cfg->fork_event, 0));
-            launch_hk_boxes(cfg->dc, db, hin, cfg->side_stream2, 1);
-            HIPCHK(hipEventRecord(cfg->join_event2, cfg->side_stream2));
-          }
-          if (has_inner) {
-            HIPCHK(hipStreamWaitEvent(cfg->side_stream, cfg->fork_event, 0));
-            launch_hk_boxes(cfg->dc, db, hin, cfg->side_stream, 2);
-            HIPCHK(hipEventRecord(cfg->join_event, cfg->side_stream));
-          }
-        } else {
-          EvScope e(cfg, st, SK_K_NEAR);
-          launch_hk_boxes(cfg->dc, db, hin, st, 3);
-        }
-        if (hin.has_far) {
-          if (!beside) { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, hin.nt, st); }
-          {
-            EvScope e(cfg, st, SK_K_FFT);
-            int rcf = run_fft_hk(cfg, hin.nt, st);
-            if (rcf) return rcf;
-          }
-          if (beside && has_near) HIPCHK(hipStreamWaitEvent(st, cfg->join_event2, 0));
-          { EvScope e(cfg, st, SK_K_INTERP); launch_hk_far(cfg->dc, cfg->d_ec, db, hin, t & 1, n, raw, st); }
-        }
-        if (hin.lag_cnt > 0) {
-          if (beside && has_inner) HIPCHK(hipStreamWaitEvent(st, cfg->join_event, 0));
-          EvScope e(cfg, st, SK_K_NEAR);
-          launch_hk_iinterp(cfg->dc, db, hin, t & 1, n, raw, st);
-        } else if (beside && has_inner) {
-          HIPCHK(hipStreamWaitEvent(st, cfg->join_event, 0));  // (never alone in practice: an inner box has lags)
-        }
-        return SK_OK;
-      }
+      if (boxes) return hk_launch_boxes(cfg, db, hin, t, n, raw, st);
       // level planning with the lag counts k_advance published: a level (and everything inside it) with at most
       // kHkNodes lags becomes the innermost one and is summed directly at those lags
       for (int l = 0; l <= L; ++l)

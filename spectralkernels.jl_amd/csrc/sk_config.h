@@ -139,6 +139,10 @@ enum { SK_ORDER_UNKNOWN = 0, SK_ORDER_SORTED = 1, SK_ORDER_UNSORTED = 2, SK_ORDE
 int h2d_doubles(sk_config* cfg, double* d_dst, const double* src, size_t cnt, hipStream_t st, int* order);
 int d2h_doubles2(sk_config* cfg, double* dst_a, double* dst_b, const double* d_src, size_t cnt_each, hipStream_t st);
 int d2h_doubles(sk_config* cfg, double* dst, const double* d_src, size_t cnt, hipStream_t st);
+// sk_api.cpp: plan and launches of one step of the Hankel path by boxes (shared by run_core and the joint march)
+int hk_plan_boxes(sk_config* cfg, DevBuffers& db, const DevState* hs, int nu, const double* a_nu, int raw, hipStream_t st,
+                  HkInner& hin, bool& boxes);
+int hk_launch_boxes(sk_config* cfg, DevBuffers& db, const HkInner& hin, int t, long long n, int raw, hipStream_t st);
 // sk_api.cpp: one march per config on device-resident lags of any order (ncfg x n results on the device, input order)
 int multi_device_core(sk_config* const* cfgs, size_t ncfg, const double* d_lags, size_t n, double k0,
                       const int* param_derivative, double** d_vals, double** d_errs);

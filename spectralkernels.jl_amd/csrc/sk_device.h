@@ -368,6 +368,12 @@ void launch_joint_strengths(const DevConst& dc, const DevBuffers& db, const Join
 void launch_bessel_joint(const DevConst& dc, const DevBuffers& db, const JointSpec& js, const JointBufs& jb, int slot, long long n,
                          hipStream_t st);
 
+// joint march through the fast Hankel transform (dim 2): (strength of transform tr, node) pairs for the Hankel kernels, and
+// the joint epilogue on the raw panel sums raw[(tr 2 + rule) n + i] that those kernels stored
+void launch_joint_pack(const DevConst& dc, const DevBuffers& db, const JointBufs& jb, int tr, double2* out, hipStream_t st);
+void launch_joint_hk_epilogue(const DevConst& dc, const DevBuffers& db, const JointSpec& js, const JointBufs& jb, const double* raw,
+                              int slot, long long n, hipStream_t st);
+
 void launch_jac_assemble(const double* vals, long long n, int ncfg, const int* map, const double* dlag, int nwarp, int t_warp,
                          int ncols, double* jac, hipStream_t st);
 

@@ -32,6 +32,23 @@ int ensure_dev_buf(void** buf, size_t* have, size_t bytes) {
 
 size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// joint_core: this lag set would take the fast Hankel transform but a step does not fit its buffers (or the route is
+// switched off): the caller runs one march per integrand instead (sk_kernel_values_multi / multi_device_core)
+constexpr int kJointHkFallback = 1000;
+// dim 2, catalogue SDFs, lag sets of hankel_min_lags and more: the joint march through the Hankel kernels (round 4).
+// Opt-in (SK_JOINT_HK=1): the joint schedule is the union of the integrands' bisection trees -- a (sub)panel is accepted
+// when EVERY integrand passes -- and in dim 2 a panel evaluation is expensive whatever the number of lags (spread + FFT of
+// the default rule).  On the nll_2d integrands at 10^5 lags the joint march takes 5 panels x 4 transforms where the four
+// separate marches take 2 + 2 + 2 + 5 panel evaluations (K' alone needs the five): 3.2-7.3 ms against 2.1 ms for the
+// separate marches side by side (tests/test_gpu_joint.py).  The default therefore stays one fast-Hankel march per
+// integrand, overlapped; integrand sets with equal schedules (K and parameter derivatives only) are where this route pays.
+bool joint_hankel_wanted(const sk_config* c0, size_t n) {
+  const char* e = getenv("SK_JOINT_HK");
+  if (!e || e[0] != '1') return false;
+  const int hk_min = c0->args.hankel_min_lags == 0 ? kHkDefaultMinLags : c0->args.hankel_min_lags;
+  return c0->args.dim == 2 && c0->args.sdf_kind != SK_SDF_CALLBACK && hk_min > 0 && n >= (size_t)hk_min && c0->hk_nb > 0;
+}
+
 }  // namespace
 
 namespace {
@@ -143,8 +160,13 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
   const size_t a8 = a256(n * 8);
   const size_t tb = sort_unique_temp_bytes((long long)n);
   const size_t fft_b = a256((size_t)ntr * 4 * n1 * sizeof(double2));
+  // Hankel route: (strength, node) pairs of one transform, raw panel sums of all transforms (2 rules x n each)
+  const bool hk_route = joint_hankel_wanted(c0, n);
+  const size_t hksrc_b = hk_route ? a256((size_t)3 * c0->M * sizeof(double2)) : 0;
+  const size_t hkraw_b = hk_route ? (size_t)(2 * ntr) * a8 : 0;
   // exactly what the pointer bumps below consume
-  const size_t need = extra_b + 3 * a8 + 256 + (a256(tb) + 256) + (size_t)(8 * nt) * a8 + (size_t)(2 * nt) * a8 + 2 * fft_b;
+  const size_t need = extra_b + 3 * a8 + 256 + (a256(tb) + 256) + (size_t)(8 * nt) * a8 + (size_t)(2 * nt) * a8 + 2 * fft_b +
+                      hksrc_b + hkraw_b;
   int rc = ensure_dev_buf(&c0->d_joint, &c0->joint_bytes, need);
   if (rc) return rc;
   char* p = (char*)c0->d_joint;
@@ -158,7 +180,9 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
   double* big = (double*)p; p += (size_t)(8 * nt) * a8;
   double* gath = (double*)p; p += (size_t)(2 * nt) * a8;  // results in input order: nt x n values, then nt x n errors
   jb.fft = (double2*)p; p += fft_b;
-  jb.fft_out = (double2*)p;
+  jb.fft_out = (double2*)p; p += fft_b;
+  double2* hk_src = (double2*)p; p += hksrc_b;
+  double* hk_raw = (double*)p;
   // ---- lags: staged upload, one sort + dedup for all integrands (src/adaptive.jl:99-120)
   int order = SK_ORDER_UNSORTED;  // device lags (pairwise distances): sorted and deduplicated below
   if (xs) {
@@ -228,6 +252,61 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
     d_fv = c0->d_jfv;
   }
   int t = 0, mode = SK_MODE_INIT, R = cb ? 1 : 2;
+  // dim 2, lag sets of hankel_min_lags and more (the unique count decides, as in run_core): every raw transform through
+  // the Hankel kernels of the single-integrand march in their raw mode, then the joint epilogue (sk_joint_kernels.inc)
+  const int hk_min = c0->args.hankel_min_lags == 0 ? kHkDefaultMinLags : c0->args.hankel_min_lags;
+  const bool hankel = hk_route && nu >= hk_min;
+  if (hk_route && !hankel) return kJointHkFallback;  // duplicates shrank the set below the threshold: the caller decides
+  if (hankel) {
+    const int nu0 = c0->args.dim / 2 - 1;
+    for (;;) {
+      const unsigned int seq = ++c0->seq;
+      launch_advance(dcj, db, mode, t, nu, k0, jb.ks0[0], seq, st);
+      // the node generation needs the device's state only: it runs while the status block travels
+      launch_gen(dcj, db, SK_MODE_ASIS, t, nu, k0, jb.ks0[0], SK_G_WEIGHT, st);
+      rc = joint_wait_status(c0, seq, st);
+      if (rc) return rc;
+      if (!xs && (c0->h_status->flags[1] & 1)) {  // device lags: the validity check ran on the unsorted input
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemsetAsync(c0->db.flags, 0, 2 * sizeof(int), st));
+        return fail(SK_EINVAL, "lags must be non-negative and finite (index pair out of range?)");
+      }
+      if (hs->done) break;
+      launch_joint_strengths(dcj, db, js, jb, t & 1, nullptr, st);  // + the integrands' tail fits and the logw boundary factor
+      // one plan per Bessel order in use: J_nu0 for the plain kernel and the parameter derivatives, J_nu0+1 for K' and
+      // slot B of a logw integrand (src/quadrature.jl:176-180,198)
+      HkInner hin[2];
+      bool have[2] = {false, false};
+      for (int r = 0; r < ntr; ++r) {
+        const int o = js.tr[r].imag ? 1 : 0;
+        if (!have[o]) {
+          bool boxes = false;
+          rc = hk_plan_boxes(c0, db, hs, nu0 + o, o ? c0->hk_a2 : c0->hk_a, SK_RAW_A, st, hin[o], boxes);
+          if (rc) return rc;
+          if (!boxes) {
+            if (t == 0) return kJointHkFallback;  // nothing evaluated yet: one march per integrand instead
+            return fail(SK_EUNSUPPORTED, "joint march (dim 2): a step does not fit the Hankel buffers");
+          }
+          have[o] = true;
+        }
+      }
+      // (the two plans differ in the series only -- same r_c, boxes and buffers -- and the transforms run one after the
+      // other on the march's stream, each with its boxes on the side streams)
+      for (int r = 0; r < ntr; ++r) {
+        const int o = js.tr[r].imag ? 1 : 0;
+        launch_joint_pack(dcj, db, jb, r, hk_src, st);
+        DevBuffers dbt = db;
+        dbt.src = hk_src;
+        dbt.lw_raw = hk_raw + (size_t)(2 * r) * sn;
+        rc = hk_launch_boxes(c0, dbt, hin[o], t, nu, SK_RAW_A, st);
+        if (rc) return rc;
+      }
+      launch_joint_hk_epilogue(dcj, db, js, jb, hk_raw, t & 1, nu, st);
+      ++t;
+      mode = SK_MODE_TRANSITION;
+      c0->stats.n_steps_launched++;
+    }
+  } else
   for (;;) {
     if (cb) {
       const unsigned int seq = ++c0->seq;
@@ -335,14 +414,22 @@ extern "C" int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const
     if (hk_min > 0 && n >= (size_t)hk_min) {
       const int rcc = joint_check_args(cfgs, ncfg);
       if (rcc) return rcc;
-      std::vector<double> k0s(ncfg, k0);
-      return sk_kernel_values_multi(cfgs, ncfg, xs, n, k0s.data(), param_derivative, vals_out, errs_out);
+      // dim 2: ONE march with every transform through the Hankel kernels (joint_core); otherwise, or when a step does
+      // not fit the Hankel buffers, one fast-Hankel march per integrand, side by side
+      if (!joint_hankel_wanted(cfgs[0], n)) {
+        std::vector<double> k0s(ncfg, k0);
+        return sk_kernel_values_multi(cfgs, ncfg, xs, n, k0s.data(), param_derivative, vals_out, errs_out);
+      }
     }
   }
   static const bool timing = getenv("SK_JOINT_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   double *dv = nullptr, *de = nullptr;
   int rc = joint_core(cfgs, ncfg, xs, nullptr, n, k0, param_derivative, &dv, &de, 0, nullptr);
+  if (rc == kJointHkFallback) {
+    std::vector<double> k0s(ncfg, k0);
+    return sk_kernel_values_multi(cfgs, ncfg, xs, n, k0s.data(), param_derivative, vals_out, errs_out);
+  }
   if (rc || n == 0) return rc;
   const auto t1 = std::chrono::steady_clock::now();
   sk_config* c0 = cfgs[0];
@@ -397,7 +484,8 @@ extern "C" int sk_kernel_jacobian_pairs(sk_config* const* cfgs, size_t ncfg, con
     JointSpec dummy;  // only ntr matters for sizing: at most two transforms per integrand
     (void)dummy;
     const size_t fft_b = a256((size_t)(2 * ncfg) * 4 * c0->dc.n1 * sizeof(double2));
-    const size_t need = 3 * a8 + tb + 512 + (size_t)(10 * ncfg) * a8 + 2 * fft_b + b_pts + b_pairs + b_lags + b_dlag + b_jac + b_map + 4096;
+    const size_t hk_b = joint_hankel_wanted(c0, npairs) ? a256((size_t)3 * c0->M * sizeof(double2)) + (size_t)(4 * ncfg) * a8 : 0;
+    const size_t need = 3 * a8 + tb + 512 + (size_t)(10 * ncfg) * a8 + 2 * fft_b + hk_b + b_pts + b_pairs + b_lags + b_dlag + b_jac + b_map + 4096;
     int rc0 = ensure_dev_buf(&c0->d_joint, &c0->joint_bytes, need);
     if (rc0) return rc0;
   }
@@ -425,15 +513,24 @@ extern "C" int sk_kernel_jacobian_pairs(sk_config* const* cfgs, size_t ncfg, con
   launch_pair_lags(d_pts, (long long)npts, pdim, (const long long*)d_pairs, (long long)npairs, d_lags, st);
   double *dv = nullptr, *de = nullptr;
   const int hk_min = c0->args.hankel_min_lags == 0 ? kHkDefaultMinLags : c0->args.hankel_min_lags;
-  if (c0->args.dim > 1 && hk_min > 0 && npairs >= (size_t)hk_min) {
-    // dim >= 2: one fast-Hankel march per integrand (the joint march sums Bessel functions directly)
+  const bool big = c0->args.dim > 1 && hk_min > 0 && npairs >= (size_t)hk_min;
+  bool separate = big && !joint_hankel_wanted(c0, npairs);
+  if (big) {
     rc = joint_check_args(cfgs, ncfg);
-    if (!rc) rc = multi_device_core(cfgs, ncfg, d_lags, npairs, k0, pd.data(), &dv, &de);
     if (rc) return rc;
-  } else {
+  }
+  if (!separate) {
+    // the joint march: dim 1 (type-3 NUFFT), small lag sets in dim >= 2 (direct Bessel sums), dim 2 above the threshold
+    // (every transform through the Hankel kernels)
     rc = joint_core(cfgs, ncfg, nullptr, d_lags, npairs, k0, pd.data(), &dv, &de, extra_bytes, &extra);
+    if (rc == kJointHkFallback) separate = true;
+    else if (rc) return rc;
+    else if (extra != (void*)c0->d_joint) return fail(SK_EHIP, "internal error: joint buffers moved");
+  }
+  if (separate) {
+    // one fast-Hankel march per integrand, side by side
+    rc = multi_device_core(cfgs, ncfg, d_lags, npairs, k0, pd.data(), &dv, &de);
     if (rc) return rc;
-    if (extra != (void*)c0->d_joint) return fail(SK_EHIP, "internal error: joint buffers moved");
   }
   if (ncols > 0) {
     launch_jac_assemble(dv, (long long)npairs, (int)ncfg, d_map, d_dlag, nwarp, t_warp, ncols, d_jac, st);
