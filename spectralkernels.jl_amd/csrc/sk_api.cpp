@@ -1043,10 +1043,11 @@ static int for_each_march(sk_config* const* cfgs, size_t ncfg, Work&& work) {
     rcs[c] = work(c);
     if (rcs[c]) msgs[c] = sk_last_error();  // the error channel is thread-local
   };
-  std::vector<std::thread> th;
-  for (size_t c = 1; c < ncfg; ++c) th.emplace_back(run, c);
-  run(0);
-  for (auto& t : th) t.join();
+  // one OpenMP thread per march: the runtime keeps its team between calls (fresh std::threads would each build -- and at
+  // their exit tear down -- an OpenMP team of their own for the staging copies inside: 9 ms per call measured instead of
+  // 2); the staging passes inside run on the march's own thread (nested parallelism is off by default)
+#pragma omp parallel for num_threads((int)ncfg) schedule(static, 1)
+  for (long long c = 0; c < (long long)ncfg; ++c) run((size_t)c);
   for (size_t c = 0; c < ncfg; ++c)
     if (rcs[c]) return fail(rcs[c], msgs[c]);
   return SK_OK;
