@@ -19,10 +19,77 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <numeric>
 #include <thread>
 #include "sk_config.h"
+
+// The shards' host threads, kept for the life of the handle: worker s runs shard s of every call (shard 0 runs on the
+// caller's thread).  Threads created per call would each build -- and tear down at their exit -- an OpenMP team for the
+// staging copies inside sk_kernel_values: milliseconds per call, more than the march of a shard (measured on the
+// overlapped marches of sk_api.cpp: 9 ms against 2).
+struct ShardPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  std::function<void(int)> job;
+  unsigned long long gen = 0;
+  int active = 0;     // workers that take part in the current generation: shards 1 .. active
+  int pending = 0;
+  bool stop = false;
+  void start(int nworkers) {
+    for (int w = 1; w <= nworkers; ++w)
+      th.emplace_back([this, w] {
+        unsigned long long seen = 0;
+        for (;;) {
+          std::function<void(int)> f;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_go.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            if (w > active) continue;
+            f = job;
+          }
+          f(w);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--pending == 0) cv_done.notify_all();
+          }
+        }
+      });
+  }
+  // runs work(0) here and work(1 .. ns-1) on the workers; returns when all are done
+  void run(int ns, const std::function<void(int)>& work) {
+    if (ns <= 1 || th.empty()) {
+      for (int s = 0; s < ns; ++s) work(s);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = work;
+      active = std::min(ns - 1, (int)th.size());
+      pending = active;
+      ++gen;
+    }
+    cv_go.notify_all();
+    work(0);
+    for (int s = active + 1; s < ns; ++s) work(s);  // (never: one worker per shard)
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  ~ShardPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_go.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
 
 struct sk_sharded {
   std::vector<sk_config*> cfgs;   // one replica per device (empty with an injected backend)
@@ -39,6 +106,7 @@ struct sk_sharded {
   std::vector<double> uxs, uvals, uerrs;  // unsorted input: unique set and its results
   std::vector<int64_t> inv;
   int split = 0;                  // 0 blocked, 1 strided
+  ShardPool pool;                 // host threads of shards 1 .. nshard-1
 };
 
 namespace {
@@ -141,6 +209,7 @@ int sk_sharded_create(sk_sharded** out, const sk_config_args* args, const int* d
   sh->ms.assign(ndev, 0.0);
   sh->lo.assign(ndev, 0);
   sh->hi.assign(ndev, 0);
+  sh->pool.start(ndev - 1);
   *out = sh;
   return warn;
 }
@@ -157,6 +226,7 @@ int sk_sharded_create_injected(sk_sharded** out, int nshard, sk_shard_fn fn, voi
   sh->ms.assign(nshard, 0.0);
   sh->lo.assign(nshard, 0);
   sh->hi.assign(nshard, 0);
+  sh->pool.start(nshard - 1);
   *out = sh;
   return SK_OK;
 }
@@ -254,14 +324,7 @@ int sk_kernel_values_sharded(sk_sharded* sh, const double* xs, size_t n, double 
     sh->ms[s] = 0.0;
     std::memset(&sh->stats[s], 0, sizeof(sk_stats));
   }
-  if (ns == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> th;
-    for (int s = 1; s < ns; ++s) th.emplace_back(work, s);
-    work(0);
-    for (auto& t : th) t.join();
-  }
+  sh->pool.run(ns, work);
   for (int s = 0; s < ns; ++s)
     if (rcs[s]) return fail(rcs[s], "shard " + std::to_string(s) + ": " + msgs[s]);
   if (order == 1) {
@@ -352,14 +415,7 @@ int sk_kernel_values_pairs_sharded(sk_sharded* sh, const double* pts, size_t npt
     sh->ms[s] = 0.0;
     std::memset(&sh->stats[s], 0, sizeof(sk_stats));
   }
-  if (ns == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> th;
-    for (int s = 1; s < ns; ++s) th.emplace_back(work, s);
-    work(0);
-    for (auto& t : th) t.join();
-  }
+  sh->pool.run(ns, work);
   for (int s = 0; s < ns; ++s)
     if (rcs[s]) return fail(rcs[s], "shard " + std::to_string(s) + ": " + msgs[s]);
   return SK_OK;
