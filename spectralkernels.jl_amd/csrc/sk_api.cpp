@@ -695,7 +695,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
 
   // ---- streaming phase of the batched march.  No round structure: the host keeps ONE step queued behind the running
   // one (the spread launch of step t reports t + 1 once it has derived its state) and stops when a spread launch
-  // reports "done" -- at most the rest of that one step is launched in vain, and the device never waits for a host
+  // reports "done" -- at most two steps are launched in vain (typically one), and the device never waits for a host
   // round trip.  Entered after the first step's k_advance (the quick marches end there), or at once when the last
   // march on this config took more than one step (then that k_advance -- 8-16 us plus a host round trip -- buys nothing).
   bool flags_up = false;
