@@ -154,7 +154,9 @@ int sk_kernel_values_device(sk_config* cfg, const double* d_xs, size_t n, double
 /* Several configs on ONE lag set -- the Jacobian pattern of src/derivatives.jl:61-112 (one kernel_values call per
  * dS/dtheta_j integrand, one with derivative=true for the warping gradients, one with logw=true for d/dalpha, all
  * at the same warp_lags).  The lags are uploaded, sorted and deduplicated once on the device; every config then
- * marches on the sorted unique set with its own integrand and the results are scattered back per config.
+ * marches on the sorted unique set with its own integrand and the results are scattered back per config.  The marches
+ * run side by side (one host thread and the config's own stream each) when all SDFs are catalogue entries and the configs
+ * are distinct; SK_MULTI_SERIAL=1 runs them one after the other -- same bits.
  * cfgs: ncfg configs on the same device; k0s / param_derivative: one entry per config (as in sk_kernel_values
  * with has_k0 = 1); vals_out / errs_out: ncfg x n, row c = config c in input order. */
 int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, const double* k0s,
@@ -167,10 +169,13 @@ int sk_kernel_values_multi(sk_config* const* cfgs, size_t ncfg, const double* xs
  * holds (src/adaptive.jl:183-198): results within tol of the separate marches of sk_kernel_values_multi, whose
  * schedules can only be shorter.  cfgs[0] must be the plain kernel (derivative = logw = 0); all configs: one dim,
  * equal quadspec / tol / alpha / criteria / tail, at most one logw integrand; one k0 for all, as the reference passes
- * it (src/derivatives.jl:57,71,81).  dim 1: type-3 NUFFT with one transform per integrand; even dim >= 2: the direct
- * Bessel sums of src/quadrature.jl:145-160 with J_nu(2 pi w r) evaluated once per (lag, node) for all integrands (lag
- * sets of hankel_min_lags and more -- 8 by default -- take one fast-Hankel march per integrand instead, here and in
- * sk_kernel_jacobian_pairs).  SDFs: all catalogue entries
+ * it (src/derivatives.jl:57,71,81).  dim 1: type-3 NUFFT with one transform per integrand; even dim >= 2: below
+ * hankel_min_lags (8 by default) lags the direct Bessel sums of src/quadrature.jl:145-160 with J_nu(2 pi w r) evaluated
+ * once per (lag, node) for all integrands; from hankel_min_lags on this entry and sk_kernel_jacobian_pairs are NOT a joint
+ * march: they run one fast-Hankel march per integrand (separate schedules, results bit-identical to separate
+ * sk_kernel_values calls), side by side on the configs' own streams.  (A joint march through the Hankel kernels exists
+ * for dim 2 -- SK_JOINT_HK=1 -- and is slower: its schedule is the union of the integrands' bisection trees)
+ * SDFs: all catalogue entries
  * (incl. sdf_dparam), evaluated on the device, or all host callbacks, each called once per panel on all its nodes
  * (no logw integrand then).  vals_out / errs_out: ncfg x n. */
 int sk_kernel_values_joint(sk_config* const* cfgs, size_t ncfg, const double* xs, size_t n, double k0,
