@@ -369,6 +369,8 @@ int hk_plan_boxes(sk_config* cfg, DevBuffers& db, const DevState* hs, int nu, co
     const long long nact = hs->hi - hs->ix1;
     hin.nu = nu;
     hk_series_fill(hin.ser, a_nu, nu);
+    for (int K = 0; K <= kHkTerms; ++K)  // K terms suffice from z = (|a_K| / thr)^(1/K) on (terms_for, per workgroup of k_hk_far)
+      hin.zterm[K] = (K >= 2 && K <= nt_full && ak[K] != 0.0) ? std::pow(std::fabs(ak[K]) / thr, 1.0 / K) : INFINITY;
     hin.pa = pa;
     hin.pb = pb;
     hin.r_hi = r_hi;

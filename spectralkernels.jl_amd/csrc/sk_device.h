@@ -70,6 +70,10 @@ struct HkInner {
   double om0, elln, r_hi;
   long long lag_lo, lag_cnt;   // the inner lags: indices [lag_lo, lag_lo + lag_cnt) of the sorted lag array
   HkSeries ser;                // Hankel's expansion of J_nu: the series NUFFT and the large-argument kernel values
+  // zterm[K], 2 <= K < nt: smallest z = 2 pi om0 r from which K series terms suffice (first omitted term no larger than the
+  // full count's at z0).  The lags are sorted: a workgroup of the far kernel whose smallest lag lies beyond it sums K terms
+  // only (round 4: most lags of a panel sit far above r_c, where half the terms are below the truncation level anyway)
+  double zterm[kHkTerms + 1];
 };
 
 // Joint march of several integrands on one lag set (sk_kernel_values_joint; src/derivatives.jl:51-112 calls
