@@ -128,9 +128,10 @@ static void build_positions(const sk_config* cfg, int variant, int rule, std::ve
   for (int64_t i = 0; i < n1; ++i) cellstart[(size_t)i + 1] = cellstart[(size_t)i] + cnt[(size_t)i + 1];
 }
 
-// Spread work list of one variant: tiles of <= 64 cells holding <= ~256 touching sources where the
-// node density allows it (Gauss nodes cluster like 1/m^2 at every sub-panel edge), heaviest first.
-static void build_tiles(const sk_config* cfg, const std::vector<int> cs[2], std::vector<int4>& tiles) {
+// Spread work list of one variant: tiles of <= maxc cells holding <= ~cap touching sources where the node density
+// allows it (Gauss nodes cluster like 1/m^2 at every sub-panel edge), heaviest first.
+static void build_tiles_geom(const sk_config* cfg, const std::vector<int> cs[2], int64_t maxc, int64_t cap,
+                             std::vector<int4>& tiles) {
   const int64_t n1 = cfg->dc.n1;
   const int W = cfg->dc.w;
   struct T { int key, start, len, cnt, jlo, jhi; };
@@ -144,7 +145,7 @@ static void build_tiles(const sk_config* cfg, const std::vector<int> cs[2], std:
     int64_t start = 0;
     while (start < n1) {
       int64_t end = start + 4 > n1 ? n1 : start + 4;
-      while (end < n1 && end - start < 64 && touching(start, end + 1) <= 256) ++end;
+      while (end < n1 && end - start < maxc && touching(start, end + 1) <= cap) ++end;
       const int64_t lo = start - W / 2 < 0 ? 0 : start - W / 2, hi = end + W / 2 > n1 ? n1 : end + W / 2;
       all.push_back({(rule << 30) | (int)start, (int)start, (int)(end - start), touching(start, end), c[(size_t)lo],
                      c[(size_t)hi]});
@@ -154,6 +155,41 @@ static void build_tiles(const sk_config* cfg, const std::vector<int> cs[2], std:
   std::stable_sort(all.begin(), all.end(), [](const T& a, const T& b) { return a.cnt > b.cnt; });
   tiles.clear();
   for (const T& t : all) tiles.push_back(make_int4(t.key, t.len, t.jlo, t.jhi));
+}
+
+// The tile geometry by the rule's size.  A tile is one workgroup's unit of latency: loads, the staging of its sources
+// (one dependent FP64 chain per source: ES weights, strength), the gather over the sources touching each cell, the
+// reduction and the write.  The default rule (n1 = 65 536) has 2 236 tiles of 64 cells / <= 256 sources for ~1 000
+// resident workgroups: big tiles amortise that chain.  A small rule has few of them -- quadspec (256, 16): 128 tiles on
+// 256 CUs, the dense ones (252 sources: every thread both the weights and the strength of a source, ten gather rounds)
+// three times as long as the light ones, and the launch ends with the slowest.  Smaller tiles (<= 128 sources: two
+// threads share a source; fewer cells: several lanes share a cell's gather) spread the same work over the idle CUs
+// until the tile count reaches about 0.6 of the resident workgroups, beyond which the replicated state prologue and the
+// halo (W cells re-staged per tile) cost more than the shorter chain saves.  Measured (tools/diag/tile_sweep.py, 10^5
+// lags, ms per call, default -> chosen): (64,4) 0.585 -> 0.55, (128,8) 0.258 -> 0.236, (256,16) 0.183 -> 0.168 and, at
+// tol 1e-12 (BASELINE config 5), 1.150 -> 1.02, (512,16) 0.163 -> 0.151, (1024,16) 0.176 -> 0.168, (2048,16) 0.208 ->
+// 0.194, (4096,16) unchanged.
+static void build_tiles(const sk_config* cfg, const std::vector<int> cs[2], int resident, std::vector<int4>& tiles) {
+  const char* ec = getenv("SK_TILE_CELLS");  // diagnostics: a fixed geometry
+  const char* es = getenv("SK_TILE_SRC");
+  if (ec || es) {
+    int64_t maxc = ec ? std::atoi(ec) : 64, cap = es ? std::atoi(es) : 256;
+    build_tiles_geom(cfg, cs, maxc < 4 ? 4 : (maxc > 64 ? 64 : maxc), cap < 16 ? 16 : cap, tiles);
+    return;
+  }
+  const size_t one_round = (size_t)(0.6 * resident), two_rounds = (size_t)(1.5 * resident);
+  static const int ladder[][2] = {{64, 128}, {64, 96}, {48, 96}, {32, 96}, {32, 64}, {16, 64}};
+  build_tiles_geom(cfg, cs, ladder[0][0], ladder[0][1], tiles);
+  if (tiles.size() > two_rounds) {  // large rules: every workgroup has several tiles anyway
+    build_tiles_geom(cfg, cs, 64, 256, tiles);
+    return;
+  }
+  std::vector<int4> next;
+  for (size_t q = 1; q < sizeof(ladder) / sizeof(ladder[0]); ++q) {
+    build_tiles_geom(cfg, cs, ladder[q][0], ladder[q][1], next);
+    if (next.size() > one_round) break;
+    tiles.swap(next);
+  }
 }
 
 static int ensure_ws(sk_config* cfg, size_t bytes) {
@@ -1211,6 +1247,11 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
     UP(v, dptr);
     cfg->d_ec = const_cast<EsConst*>(dptr);
   }
+  int cus = 256;
+  {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && v > 0) cus = v;
+  }
   for (int variant = 0; variant < 2; ++variant) {
     if (variant == 1 && cfg->p == 0.0) {
       for (int rule = 0; rule < 2; ++rule) {
@@ -1229,7 +1270,7 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
       UP(cs2[rule], dc.cellstart[variant][rule]);
     }
     std::vector<int4> tiles;
-    build_tiles(cfg, cs2, tiles);
+    build_tiles(cfg, cs2, 4 * cus, tiles);
     UP(tiles, dc.tiles[variant]);
     dc.ntiles[variant] = (int)tiles.size();
   }

@@ -26,7 +26,7 @@ static const size_t kSerialMax = (size_t)1 << 14;   // below this many doubles o
 
 static int copy_threads() {
   static int t = [] {
-    int v = 8;
+    int v = sk::host_threads(8);  // no more than the process may run at once (affinity, cgroup quota)
     if (const char* e = getenv("SK_COPY_THREADS")) v = atoi(e);
     return v < 1 ? 1 : (v > 32 ? 32 : v);
   }();

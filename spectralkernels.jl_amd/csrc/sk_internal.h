@@ -49,6 +49,13 @@ double es_phi(double z, int w, double beta);
 double es_phi_hat(double xi, int w, double beta);
 void build_es_tables(int w, int64_t n1, int64_t n2, double theta_max, EsTables& t);
 
+// ---------------------------------------------------------------- host threads
+// CPUs this process may really use: the smaller of its affinity mask and its cgroup CPU quota (cpu.max / cfs_quota_us),
+// at most `cap`.  A container that shows 256 logical CPUs under a quota of 16 throttles a 256-thread OpenMP team --
+// and, while its workers spin out their block time, everything else in the process -- for the rest of each 100 ms
+// scheduler period (measured: config creation 100-300 ms instead of 15, one call in eight stalled for 90 ms).
+int host_threads(int cap);
+
 // ---------------------------------------------------------------- error channel
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);

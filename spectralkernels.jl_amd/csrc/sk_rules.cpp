@@ -5,13 +5,48 @@
 // as starting values (Legendre: the classical cosine guess), then Newton on the three-term
 // recurrence in long double, weights from the derivative formula
 //   w_j = 2^(p+1) / ((1 - x_j^2) P_n'(x_j)^2)            (alpha = 0, beta = p).
+#include <sched.h>
 #include <cmath>
+#include <cstdio>
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <thread>
 #include "sk_internal.h"
 
 namespace sk {
+
+int host_threads(int cap) {
+  static const int avail = [] {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = CPU_COUNT(&set);
+    // cgroup v2: "<quota> <period>" or "max <period>"; v1: two files, quota -1 = unlimited
+    long long quota = -1, period = 0;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0};
+      if (std::fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm') quota = std::atoll(q);
+      std::fclose(f);
+    } else {
+      if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (std::fscanf(g, "%lld", &quota) != 1) quota = -1;
+        std::fclose(g);
+      }
+      if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (std::fscanf(g, "%lld", &period) != 1) period = 0;
+        std::fclose(g);
+      }
+    }
+    if (quota > 0 && period > 0) {
+      const int q = (int)((quota + period - 1) / period);
+      if (q < n) n = q;
+    }
+    return n < 1 ? 1 : n;
+  }();
+  return cap > 0 && cap < avail ? cap : avail;
+}
+
 namespace {
 
 typedef long double ld;
@@ -99,7 +134,7 @@ void gauss_rule(int64_t n, double p, std::vector<double>& nodes, std::vector<dou
   weights.assign(n, 0.0);
   if (p == 0.0) {
     const int64_t half = (n + 1) / 2;
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(host_threads(8))
     for (int64_t j = 0; j < half; ++j) {
       // j-th largest root
       ld x = cosl(3.14159265358979323846264338327950288L * (j + 0.75L) / (n + 0.5L));
@@ -136,7 +171,7 @@ void gauss_rule(int64_t n, double p, std::vector<double>& nodes, std::vector<dou
     std::sort(d.begin(), d.end());
     const ld bl = (ld)p;
     const ld c0 = powl(2.0L, bl + 1.0L);
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(host_threads(8))
     for (int64_t j = 0; j < n; ++j) {
       ld x = d[j], pn, dpn;
       for (int it = 0; it < 50; ++it) {

@@ -121,7 +121,7 @@ void block_of(int64_t n, int s, int ns, int64_t& lo, int64_t& hi) {
 // 0: strictly increasing and valid, 1: not strictly increasing, 2: a negative / NaN lag
 int scan_lags(const double* xs, size_t n) {
   int uns = 0, bad = 0;
-#pragma omp parallel for reduction(| : uns, bad) schedule(static) num_threads(8)
+#pragma omp parallel for reduction(| : uns, bad) schedule(static) num_threads(sk::host_threads(8))
   for (long long i = 0; i < (long long)n; ++i) {
     bad |= !(xs[i] >= 0.0);
     if (i + 1 < (long long)n) uns |= !(xs[i] < xs[i + 1]);
@@ -134,7 +134,7 @@ int scan_lags(const double* xs, size_t n) {
 void host_sort_unique(const double* xs, size_t n, std::vector<double>& uxs, std::vector<int64_t>& inv) {
   struct KV { double x; int64_t i; };
   std::vector<KV> a(n), b(n);
-  int T = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+  int T = sk::host_threads(16);
   while (T > 1 && n / T < 4096) T /= 2;
   int P = 1;
   while (P * 2 <= T) P *= 2;  // power of two chunks
@@ -201,7 +201,7 @@ int sk_sharded_create(sk_sharded** out, const sk_config_args* args, const int* d
     }
     if (rc == SK_WARN_QUADSPEC) warn = rc;
     // the staging threads of all shards run at once: share the cores (8 per shard alone would be 64 on an 8-GPU node)
-    c->copy_threads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency() / std::max(1, ndev)));
+    c->copy_threads = std::max(1, std::min(8, sk::host_threads(0) / std::max(1, ndev)));
     sh->cfgs.push_back(c);
     sh->devices.push_back(dev);
   }
@@ -329,7 +329,7 @@ int sk_kernel_values_sharded(sk_sharded* sh, const double* xs, size_t n, double 
     if (rcs[s]) return fail(rcs[s], "shard " + std::to_string(s) + ": " + msgs[s]);
   if (order == 1) {
     const int64_t* inv = sh->inv.data();
-#pragma omp parallel for schedule(static) num_threads(8)
+#pragma omp parallel for schedule(static) num_threads(sk::host_threads(8))
     for (long long i = 0; i < (long long)n; ++i) {
       vals_out[i] = uv[inv[i]];
       errs_out[i] = ue[inv[i]];

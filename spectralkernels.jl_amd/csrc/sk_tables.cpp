@@ -105,7 +105,7 @@ void build_es_tables(int w, int64_t n1, int64_t n2, double theta_max, EsTables& 
   // ---- Fourier transform tables
   HatQuad h = make_hat_quad(w, beta);
   t.deconv.resize((size_t)(n1 / 2 + 1));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(host_threads(8))
   for (int64_t l = 0; l <= n1 / 2; ++l)
     t.deconv[l] = (double)(1.0L / hat_eval(h, 2.0L * PI_L * (ld)l / (ld)n2));
   // 1/phi_hat(theta) ~ sum_k cheb[k] T_k(2 (theta/theta_max)^2 - 1)
