@@ -1238,6 +1238,14 @@ int sk_config_create(sk_config** out, const sk_config_args* args) {
   UP(cfg->leg[0], dc.leg_no1); UP(cfg->leg[1], dc.leg_wt1); UP(cfg->leg[2], dc.leg_no2); UP(cfg->leg[3], dc.leg_wt2);
   UP(cfg->jac[0], dc.jac_no1); UP(cfg->jac[1], dc.jac_wt1); UP(cfg->jac[2], dc.jac_no2); UP(cfg->jac[3], dc.jac_wt2);
   UP(cfg->tab.deconv, dc.deconv);
+  {
+    std::vector<double2> otw((size_t)(dc.n1 / 2 + 1));
+    for (int64_t l = 0; l <= dc.n1 / 2; ++l) {
+      const long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)l / (long double)dc.n2;
+      otw[(size_t)l] = make_double2((double)cosl(a), (double)sinl(a));
+    }
+    UP(otw, dc.otw);
+  }
   std::memset(&cfg->ec, 0, sizeof(cfg->ec));
   std::memcpy(cfg->ec.poly, cfg->tab.poly.data(), cfg->tab.poly.size() * sizeof(double));
   std::memcpy(cfg->ec.cheb, cfg->tab.cheb.data(), cfg->tab.cheb.size() * sizeof(double));

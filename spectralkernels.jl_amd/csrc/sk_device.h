@@ -127,6 +127,7 @@ struct DevConst {
   const double* pos[2][2];      // [variant][rule] source positions in grid units, P_j in [w/2, n1-w/2]
   const int* cellstart[2][2];   // [variant][rule] first source with floor(P_j) >= cell, n1+1 entries
   const double* deconv;         // n1/2+1 values of 1/phi_hat(2 pi l/n2)
+  const double2* otw;           // n1/2+1 values of e^{2 pi i l/n2}: the twiddle of the odd output samples (k_spread_b)
   // spread work list per variant: {rule << 30 | first cell, cells <= 64, first source, end source}
   // sorted by decreasing source count, so that the dense sub-panel-edge tiles start first
   const int4* tiles[2];

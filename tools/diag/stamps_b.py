@@ -26,6 +26,13 @@ d = np.diff(t, axis=1)
 print("items", len(a), "(ticks of s_memtime = 100 MHz: 1 tick = 10 ns); kb of the stamped step:", np.unique(a[:, 7]))
 print("item phase means: loads+barrier %.1f  stage0 %.1f  gather0 %.1f  rest %.1f  total %.1f" % (
     d[:, 0].mean(), d[:, 1].mean(), d[:, 2].mean(), d[:, 3].mean(), (t[:, 4] - t[:, 0]).mean()))
+tot = t[:, 4] - t[:, 0]
+nd = 8
+print("item total by position in the (heaviest-first) list, octiles:", [int(tot[i * len(tot) // nd:(i + 1) * len(tot) // nd].mean()) for i in range(nd)])
+print("   sources per item, octiles:", [int(a[i * len(a) // nd:(i + 1) * len(a) // nd, 5].mean()) for i in range(nd)],
+      " cells:", [int(a[i * len(a) // nd:(i + 1) * len(a) // nd, 6].mean()) for i in range(nd)])
+for nm, col in (("loads", 0), ("stage0", 1), ("gather0", 2), ("rest", 3)):
+    print("   %-8s octiles:" % nm, [int(d[i * len(d) // nd:(i + 1) * len(d) // nd, col].mean()) for i in range(nd)])
 w = raw[6000:8000]
 w = w[w[:, 0] > 0].astype(np.int64)
 t0 = w[:, 0].min()
