@@ -102,6 +102,22 @@ def reference_probe():
     return ("available" if ok else "unavailable"), found
 
 
+def cpu_quota():
+    """CPUs the cgroup lets this job use at once (cpu.max / cfs_quota_us), or None.  The GPU boxes show 256 logical CPUs
+    under a quota of 16: a 64-thread run of the port is throttled, not slow (VERDICT r3 weak #11)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, -(-int(q) // int(per)))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, -(-q // per))
+    except Exception:
+        return None
+
+
 def kernels_sha():
     """Identity of the kernel sources a PMC / instruction-mix summary under profiles/ belongs to."""
     import hashlib
@@ -474,9 +490,12 @@ def main():
         from oracle import sk_oracle as o
         ref_state, ref_found = reference_probe()
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        # thread count of the port: the box may expose far more logical CPUs than this job's share of them (an
-        # over-subscribed run was 17x slower); one trial run each at 16 and 64 threads (capped), keep the faster
-        cands = sorted({min(avail, 16), min(avail, 64)})
+        quota = cpu_quota()
+        usable = min(avail, quota) if quota else avail
+        # thread count of the port: the box may expose far more logical CPUs than this job's share of them (the cgroup
+        # quota: an over-subscribed run is throttled -- 17x slower once); one trial run each at 16 and 64 threads, both
+        # capped at what the job may use, keep the faster
+        cands = sorted({min(usable, 16), min(usable, 64)})
         trial = {}
         fast_ok = w["kw"].get("dim", 1) == 1  # the oracle has no fast Hankel transform: dim >= 2 is direct sums only
         for T in cands:
@@ -515,6 +534,7 @@ def main():
                              "Hankel transform), %.1f s" % (idx.size, n, tdir),
                    "max_abs_diff_vs_gpu_over_k0": float(np.abs(dks - ks[idx]).max() / abs(k0))}
         cpu["logical_cpus"] = avail
+        cpu["cpu_quota"] = quota  # CPUs the cgroup grants at once (None: no quota): the ceiling of any thread count
         cpu["thread_trials_s"] = {str(k): round(v, 3) for k, v in trial.items()}
         cpu["reference"] = ref_state  # Julia + FINUFFT (README.md:38-48) on this box?
         cpu["reference_probe"] = ref_found

@@ -180,8 +180,11 @@ static void build_tiles(const sk_config* cfg, const std::vector<int> cs[2], int 
   const size_t one_round = (size_t)(0.6 * resident), two_rounds = (size_t)(1.5 * resident);
   static const int ladder[][2] = {{64, 128}, {64, 96}, {48, 96}, {32, 96}, {32, 64}, {16, 64}};
   build_tiles_geom(cfg, cs, ladder[0][0], ladder[0][1], tiles);
-  if (tiles.size() > two_rounds) {  // large rules: every workgroup has several tiles anyway
-    build_tiles_geom(cfg, cs, 64, 256, tiles);
+  if (tiles.size() > two_rounds) {
+    // large rules.  dim 1: every workgroup has several tiles anyway, big ones amortise best.  dim >= 2 (k_spread_multi:
+    // one workgroup per tile, batches of 128 sources carrying every series term): a tile of <= 128 sources is one batch
+    // -- 44 -> 28.5 us per launch on BASELINE config 4
+    if (cfg->dc.dim == 1) build_tiles_geom(cfg, cs, 64, 256, tiles);
     return;
   }
   std::vector<int4> next;
@@ -988,7 +991,7 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
   long long* d_nu = (long long*)base; base += 256;
   long long nu = 0;
   int was_unsorted = 1, bad_lags = 0;
-  if (sort_unique_sync(d_xs, (long long)n, uxs, inv, d_nu, cfg->h_nuniq, base, tb, st, &nu, &was_unsorted, &bad_lags))
+  if (sort_unique_sync(d_xs, (long long)n, uxs, inv, d_nu, cfg->h_nuniq, base, tb, st, &nu, &was_unsorted, &bad_lags, true))
     return fail(SK_EHIP, "sort failed");
   cfg->stats.n_syncs++;
   if (sort_first) {
@@ -1035,7 +1038,8 @@ int sort_unique_on_device(sk_config* cfg, const double* xs, size_t n, std::vecto
   rc = h2d_doubles(cfg, d_xs, xs, n, st, nullptr);
   if (rc) return rc;
   long long nu_ll = 0;
-  if (sort_unique_sync(d_xs, (long long)n, d_ux, d_inv, d_nu, cfg->h_nuniq, tmp, tb, st, &nu_ll)) return fail(SK_EHIP, "sort failed");
+  if (sort_unique_sync(d_xs, (long long)n, d_ux, d_inv, d_nu, cfg->h_nuniq, tmp, tb, st, &nu_ll, nullptr, nullptr, true))
+    return fail(SK_EHIP, "sort failed");
   const size_t nu = (size_t)nu_ll;
   uxs.resize(nu);
   inv.resize(n);

@@ -405,7 +405,7 @@ void sort_unique(const double* xs, long long n, double* uxs, long long* inv, lon
 // sort_unique + the count on the host (synchronises `st`; h_nu pinned); the library sort when the bucket sort gave up
 int sort_unique_sync(const double* xs, long long n, double* uxs, long long* inv, long long* d_n_unique, long long* h_nu,
                      void* temp, size_t temp_bytes, hipStream_t st, long long* nu, int* was_unsorted = nullptr,
-                     int* invalid = nullptr);  // h_nu: 3 pinned words
+                     int* invalid = nullptr, bool early = false);  // h_nu: 3 pinned words
 void launch_gather(const double* ks, const double* errs, const long long* inv, long long n, double* vals, double* errs_out,
                    hipStream_t st);
 

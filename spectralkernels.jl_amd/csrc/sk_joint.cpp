@@ -198,7 +198,8 @@ int joint_core(sk_config* const* cfgs, size_t ncfg, const double* xs, const doub
   const bool sorted = (order == SK_ORDER_SORTED);
   const double* lags = d_xs;
   if (!sorted) {
-    if (sort_unique_sync(d_xs, (long long)n, uxs, inv, d_nu, c0->h_nuniq, tmp, tb, st, &nu)) return fail(SK_EHIP, "sort failed");
+    if (sort_unique_sync(d_xs, (long long)n, uxs, inv, d_nu, c0->h_nuniq, tmp, tb, st, &nu, nullptr, nullptr, true))
+      return fail(SK_EHIP, "sort failed");
     lags = uxs;
   }
   const size_t sn = (size_t)nu;

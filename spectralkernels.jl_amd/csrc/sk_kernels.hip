@@ -17,6 +17,7 @@
 #include <cstring>
 #include <cmath>
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <rocprim/rocprim.hpp>
 #include "sk_device.h"
 #include "sk_lean_math.h"
@@ -2755,10 +2756,22 @@ __global__ void __launch_bounds__(256) k_bk_sort_big(const ulonglong2* rec, cons
 }
 // first unique index of every bucket (exclusive scan of the distinct-key counts) and the number of unique lags; a bucket
 // sort that overflowed reports -1 (sort_unique_sync then sorts with the library)
-__global__ void __launch_bounds__(1024) k_bk_uscan(const int* ucount, int* ubase, const BkState* stt, long long* n_unique) {
+// h_pub (pinned host memory, may be null): the count, the input-check flags beside it and `seq` go to the host from
+// here -- the host then knows the number of unique lags while k_bk_finish still runs (sort_unique_sync, early)
+__device__ __forceinline__ void bk_publish(long long* n_unique, long long nu, long long* h_pub, long long seq) {
+  *n_unique = nu;
+  if (h_pub) {
+    h_pub[0] = nu;
+    h_pub[2] = n_unique[2];  // [unsorted, invalid] of k_make_keys
+    __threadfence_system();
+    __hip_atomic_store(&h_pub[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ void __launch_bounds__(1024) k_bk_uscan(const int* ucount, int* ubase, const BkState* stt, long long* n_unique,
+                                                   long long* h_pub, long long seq) {
   __shared__ int part[1024];
   if (stt->overflow) {
-    if (threadIdx.x == 0) *n_unique = -1;
+    if (threadIdx.x == 0) bk_publish(n_unique, -1, h_pub, seq);
     return;
   }
   constexpr int PER = kBkN / 1024;
@@ -2782,7 +2795,7 @@ __global__ void __launch_bounds__(1024) k_bk_uscan(const int* ucount, int* ubase
     ubase[threadIdx.x * PER + q] = run;
     run += loc[q];
   }
-  if (threadIdx.x == 1023) *n_unique = run;
+  if (threadIdx.x == 1023) bk_publish(n_unique, run, h_pub, seq);
 }
 // unique lags and the inverse map, one wave per bucket (what k_heads / scan / k_scatter_unique do for the library sort)
 __global__ void __launch_bounds__(256) k_bk_finish(const unsigned long long* keys, const long long* perm, const int* code,
@@ -2818,8 +2831,9 @@ size_t sort_unique_temp_bytes(long long n) {
 }
 
 // use_lib = false: bucket sort first; *d_n_unique = -1 if it overflowed (call again with use_lib = true)
-void sort_unique(const double* xs, long long n, double* uxs, long long* inv, long long* d_n_unique, void* temp,
-                 size_t temp_bytes, hipStream_t st, bool use_lib) {
+// returns true if the count is published to h_pub by the sort itself (bucket path with h_pub given)
+bool sort_unique(const double* xs, long long n, double* uxs, long long* inv, long long* d_n_unique, void* temp,
+                 size_t temp_bytes, hipStream_t st, bool use_lib, long long* h_pub = nullptr, long long seq = 0) {
   char* base = (char*)temp;
   const size_t arr = align_up((size_t)n * 8);
   unsigned long long* keys_in = (unsigned long long*)base; base += arr;
@@ -2857,24 +2871,46 @@ void sort_unique(const double* xs, long long n, double* uxs, long long* inv, lon
     int* ubase = (int*)idx_in;
     hipLaunchKernelGGL(k_bk_sort_wave, dim3(kBkN / 4), dim3(256), 0, st, rec, starts, stt, keys_out, idx_out, code, ucount);
     hipLaunchKernelGGL(k_bk_sort_big, dim3(kBkN / 64), dim3(256), 0, st, rec, starts, stt, keys_out, idx_out, code, ucount);
-    hipLaunchKernelGGL(k_bk_uscan, dim3(1), dim3(1024), 0, st, ucount, ubase, stt, d_n_unique);
+    hipLaunchKernelGGL(k_bk_uscan, dim3(1), dim3(1024), 0, st, ucount, ubase, stt, d_n_unique, h_pub, seq);
     hipLaunchKernelGGL(k_bk_finish, dim3(kBkN / 4), dim3(256), 0, st, keys_out, idx_out, code, starts, ubase, stt, uxs, inv);
-    return;
+    return h_pub != nullptr;
   }
   hipLaunchKernelGGL(k_heads, dim3(nblk(n, 256)), dim3(256), 0, st, keys_out, n, head);
   sb = lib_bytes;
   (void)rocprim::inclusive_scan(lib, sb, head, uid1, (size_t)n, rocprim::plus<long long>(), st);
   hipLaunchKernelGGL(k_scatter_unique, dim3(nblk(n, 256)), dim3(256), 0, st, keys_out, idx_out, uid1, n, uxs, inv,
                      d_n_unique, (const int*)nullptr);
+  return false;
 }
 
+// early: return as soon as the number of unique lags is known -- the bucket sort publishes it from k_bk_uscan, one launch
+// (k_bk_finish: the unique lags and the inverse map) before the sort ends; what the caller enqueues on `st` next queues
+// behind that launch instead of waiting for a copy, a stream synchronisation and a launch (24 us of idle device per
+// call on BASELINE config 4).  Only for callers whose next consumer of uxs / inv is stream-ordered on `st`.
 int sort_unique_sync(const double* xs, long long n, double* uxs, long long* inv, long long* d_n_unique, long long* h_nu,
-                     void* temp, size_t temp_bytes, hipStream_t st, long long* nu, int* was_unsorted, int* invalid) {
+                     void* temp, size_t temp_bytes, hipStream_t st, long long* nu, int* was_unsorted, int* invalid, bool early) {
+  static std::atomic<long long> g_seq{0};
   for (int pass = 0; pass < 2; ++pass) {
-    sort_unique(xs, n, uxs, inv, d_n_unique, temp, temp_bytes, st, pass == 1);
-    if (hipMemcpyAsync(h_nu, d_n_unique, 3 * sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
+    const long long seq = ++g_seq;
+    const bool published = sort_unique(xs, n, uxs, inv, d_n_unique, temp, temp_bytes, st, pass == 1, early ? h_nu : nullptr, seq);
+    if (published) {
+      volatile long long* p = h_nu + 3;
+      unsigned long long spins = 0;
+      while (*p != seq) {
+        if ((++spins & 0x3fff) == 0) {
+          const hipError_t q = hipStreamQuery(st);
+          if (q == hipSuccess) {
+            if (*p == seq) break;
+            return 1;  // the stream drained without the count
+          }
+          if (q != hipErrorNotReady) return 1;
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    } else if (hipMemcpyAsync(h_nu, d_n_unique, 3 * sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+               hipStreamSynchronize(st) != hipSuccess) {
       return 1;
+    }
     if (*h_nu >= 0) break;
   }
   *nu = *h_nu;
