@@ -516,14 +516,22 @@ int hk_launch_boxes(sk_config* cfg, DevBuffers& db, const HkInner& hin, int t, l
     // the far kernel waits for, and only a panel that starts below om0 has one -- and the longer chain of the
     // inner box, which only the interpolation of the lags up to r_c waits for
     HIPCHK(hipEventRecord(cfg->fork_event, st));
+    if (has_near) HIPCHK(hipStreamWaitEvent(cfg->side_stream2, cfg->fork_event, 0));
+    if (has_inner) HIPCHK(hipStreamWaitEvent(cfg->side_stream, cfg->fork_event, 0));
     launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, hin.nt, st);
+    {
+      // the FFT is enqueued before the boxes' seven launches: issued behind them it reached the device 45 us after the
+      // spread launch had ended (a launch costs the host 4-6 us; the far kernel waits for the FFT, not for the host).
+      // Tried: the boxes' streams at the lowest priority (0.632 against 0.60-0.62 ms), the inner box's chain started
+      // behind the spread (equal) or behind the FFT (0.68 ms).
+      int rcf = run_fft_hk(cfg, hin.nt, st);
+      if (rcf) return rcf;
+    }
     if (has_near) {
-      HIPCHK(hipStreamWaitEvent(cfg->side_stream2, cfg->fork_event, 0));
       launch_hk_boxes(cfg->dc, db, hin, cfg->side_stream2, 1);
       HIPCHK(hipEventRecord(cfg->join_event2, cfg->side_stream2));
     }
     if (has_inner) {
-      HIPCHK(hipStreamWaitEvent(cfg->side_stream, cfg->fork_event, 0));
       launch_hk_boxes(cfg->dc, db, hin, cfg->side_stream, 2);
       HIPCHK(hipEventRecord(cfg->join_event, cfg->side_stream));
     }
@@ -532,8 +540,8 @@ int hk_launch_boxes(sk_config* cfg, DevBuffers& db, const HkInner& hin, int t, l
     launch_hk_boxes(cfg->dc, db, hin, st, 3);
   }
   if (hin.has_far) {
-    if (!beside) { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, hin.nt, st); }
-    {
+    if (!beside) {
+      { EvScope e(cfg, st, SK_K_SPREAD); launch_hk_spread(cfg->dc, cfg->d_ec, db, t & 1, hin.om0, hin.nt, st); }
       EvScope e(cfg, st, SK_K_FFT);
       int rcf = run_fft_hk(cfg, hin.nt, st);
       if (rcf) return rcf;
