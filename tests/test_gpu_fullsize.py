@@ -244,3 +244,31 @@ def test_roctx_ranges_and_copy_thread_settings_do_not_change_results(sk):
     cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(1, 1, 1.5), quadspec=(256, 16))
     ks, es = sk.kernel_values(cfg, 10.0 ** np.linspace(-5, 0, 70000), k0=np.pi / 2)
     assert a == float(ks.sum()) and b == float(es.sum())
+
+
+def test_many_configs_in_one_process_have_no_stalled_calls(sk):
+    """A fitting loop rebuilds its config every iteration (gen_new_sdf_config, src/adaptive.jl:69-72).  On a box whose
+    cgroup grants fewer CPUs than it shows (the GPU boxes: 16 of 256), an OpenMP team sized by the visible CPUs was
+    throttled by the kernel's scheduler: config creation took 100-300 ms instead of 15 and one call in eight stalled for
+    90 ms (tools/diag/cfg_churn.py).  host_threads (sk_rules.cpp) sizes every team by the quota; this guards it: no call
+    may take 25 x the median, and creating a config whose rules are cached stays under 80 ms."""
+    import time
+    n = 10 ** 5
+    rs = np.linspace(0.0, 5.1, n)
+    d_rs, d_ks, d_es = sk.DeviceArray.from_host(rs), sk.DeviceArray(n), sk.DeviceArray(n)
+    calls, creates = [], []
+    for i in range(8):
+        t0 = time.perf_counter()
+        cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(2.14, 0.97, 0.89 + 0.01 * i), tol=1e-10, quadspec=(256, 16))
+        creates.append(time.perf_counter() - t0)
+        k0 = sk.compute_k0(cfg)
+        for _ in range(8):
+            t0 = time.perf_counter()
+            sk.kernel_values_device(cfg, d_rs.ptr, n, k0, d_ks.ptr, d_es.ptr)
+            sk.synchronize()
+            calls.append(time.perf_counter() - t0)
+        del cfg
+    calls = np.array(calls[8:])  # the first config's calls include one-off initialisation
+    med = float(np.median(calls))
+    assert calls.max() < 25 * med, (med, np.sort(calls)[-5:])
+    assert max(creates[1:]) < 0.08, creates
