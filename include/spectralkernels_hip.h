@@ -129,6 +129,10 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
 /* Wall-clock split of the last sk_kernel_values call on this config, in ms: [0] staged upload of the lags
  * (enqueue side), [1] march, [2] download into the caller's arrays, [3] whole call. */
 int sk_last_host_timing(const sk_config* cfg, double* ms4);
+/* Automatic batch width, last march on this config: [0] steps launched with the one-panel kernels inside a full-width march
+ * (while the march retires lags every step is one fresh outer panel, src/adaptive.jl:149-199: the lighter instantiations
+ * evaluate it with the same bits), [1] steps those launches skipped and the host launched again at the full width. */
+int sk_last_step_kinds(const sk_config* cfg, long long* out2);
 
 /* Memory owned by the library's HIP runtime, so that a caller (the Julia shim, tests, bench.py) needs no HIP
  * binding of its own.  sk_host_alloc returns PINNED host memory: arrays that live in it are copied by DMA

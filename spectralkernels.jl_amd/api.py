@@ -593,6 +593,14 @@ def host_timing(config):
     return dict(upload_ms=t[0], march_ms=t[1], download_ms=t[2], total_ms=t[3])
 
 
+def step_kinds(config):
+    """Automatic batch width, last march: steps launched with the one-panel kernels inside a full-width march and steps
+    those launches skipped (launched again at the full width) -- sk_last_step_kinds."""
+    o = (C.c_longlong * 2)()
+    _check(L.load().sk_last_step_kinds(config._h, o))
+    return dict(one_panel_launches=int(o[0]), skipped=int(o[1]))
+
+
 class ShardedKernelConfig:
     """One process driving several GPUs: a replica of the config per device, the sorted unique lag set cut into
     contiguous blocks (sk_sharded_create / sk_kernel_values_sharded).  `backend`: CPU-tier test hook replacing the

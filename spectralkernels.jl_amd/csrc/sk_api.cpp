@@ -251,7 +251,8 @@ static const bool g_no_fuse = getenv("SK_NO_FUSE") != nullptr;  // diagnostics: 
 static const bool g_debug_hk = getenv("SK_DEBUG_HK") != nullptr;    // diagnostics: the plan of every Hankel step
 static const bool g_hk_serial = getenv("SK_HK_SERIAL") != nullptr;  // diagnostics: Hankel boxes on the march's stream
 static const bool g_no_stream = getenv("SK_NO_STREAM") != nullptr;  // diagnostics: rounds with k_advance throughout
-static const bool g_debug_batch = getenv("SK_DEBUG_BATCH") != nullptr;  // diagnostics: one step per round, every state printed
+static const bool g_debug_batch = getenv("SK_DEBUG_BATCH") != nullptr;
+static const bool g_no_hybrid = getenv("SK_NO_HYBRID") != nullptr;  // diagnostics: no one-panel launches inside a full-width march  // diagnostics: one step per round, every state printed
 static const char* const k_names[SK_K_COUNT] = {"k_gen", "k_spread", "rocfft", "k_interp", "k_advance", "k_hk_near"};
 
 // SK_ROCTX=1: roctx ranges named after the reference's @timeit sections (src/adaptive.jl:156-199,
@@ -345,8 +346,8 @@ static int run_fft_hk(sk_config* cfg, int nt, hipStream_t st) {
   return SK_OK;
 }
 
-static int run_fft_b(sk_config* cfg, hipStream_t st) {
-  const bool one = cfg->dc.K == 1 && cfg->plan_b1;
+static int run_fft_b(sk_config* cfg, hipStream_t st, bool one_panel = false) {
+  const bool one = (one_panel || cfg->dc.K == 1) && cfg->plan_b1;
   rocfft_execution_info info = one ? cfg->info_b1 : cfg->info_b;
   FFTCHK(rocfft_execution_info_set_stream(info, st));
   void* in[1] = {cfg->db.bfft};
@@ -646,16 +647,31 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   // the panel sums instead of running the epilogue
   unsigned int stream_seq = 0;  // != 0: streaming phase of the batched march (see below)
   bool gen_ahead = false;
+  // One-panel launches inside a full-width march (automatic batch width only).  While the march retires lags every step
+  // is one fresh outer panel (the "peel": 29 of BASELINE config 5's 33 steps); the K = 1 instantiations evaluate such a
+  // step with the same bits as the full width's and ~3 us sooner.  The spread launch of step t says whether step t was
+  // of that kind (HostStatus::peel_hint, stored ahead of `progress`); if so the host launches step t + 1 with the
+  // one-panel kernels, which evaluate it only if it is of that kind too and otherwise skip it (HostStatus::need_wide;
+  // the host launches it again at the full width).  Every decision is a function of device-published state of the
+  // step before -- never of timing -- and every evaluated step has the full width's bits: the result is the full-width
+  // march's, bit for bit (tests/test_gpu_batched.py).  After two skipped steps a call stays at the full width.
+  const bool hybrid_ok = batched && cfg->k_adaptive && cfg->k_full > 1 && cfg->dc.K == cfg->k_full && cfg->plan_b1 && !g_no_hybrid;
+  bool narrow_step = false;
+  DevConst dcn = cfg->dc;
+  dcn.K = 1;
+  dcn.Kv = 0;
+  dcn.hybrid = 1;
   auto eval_pass = [&](int g, int nu, int raw, std::vector<double>& hv) -> int {
     if (cb) {
       int rc = upload_fvals(g, hv);
       if (rc) return rc;
     }
     if (batched) {
-      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread_b(cfg->dc, cfg->d_ec, db, mode, t, n, k0, ks0, stream_seq, st); }
+      const DevConst& dcl = narrow_step ? dcn : cfg->dc;
+      { EvScope e(cfg, st, SK_K_SPREAD); launch_spread_b(dcl, cfg->d_ec, db, mode, t, n, k0, ks0, stream_seq, st); }
       {
         EvScope e(cfg, st, SK_K_FFT);
-        int rc = run_fft_b(cfg, st);
+        int rc = run_fft_b(cfg, st, narrow_step);
         if (rc) return rc;
       }
       if (lags_ready) {  // first evaluation: from here on every lag is read
@@ -663,7 +679,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         lags_ready = nullptr;
         if (check_flags) launch_check_sorted(d_uxs, n, db.flags, st);
       }
-      { EvScope e(cfg, st, SK_K_INTERP); launch_interp_b(cfg->dc, cfg->d_ec, db, t & 1, n, st); }
+      { EvScope e(cfg, st, SK_K_INTERP); launch_interp_b(dcl, cfg->d_ec, db, t, n, st); }
       return SK_OK;
     }
     if (gen_ahead) gen_ahead = false;  // issued behind k_advance, ahead of the host round trip
@@ -753,12 +769,23 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
     volatile unsigned int* prog = &cfg->h_status->progress;
     volatile unsigned int* dseq = &cfg->h_status->done_seq;
     volatile int* hflags = cfg->h_status->flags;
+    volatile unsigned int* hint = &cfg->h_status->peel_hint;
+    volatile unsigned int* need = &cfg->h_status->need_wide;
     const int t_first = t;
+    *hint = 0u;
+    *need = 0u;
     *prog = (unsigned int)t;
     const int depth = 1;  // launched-but-not-started steps: one queued behind the running one
     unsigned long long spins = 0;
+    int skips = 0;
+    bool again_wide = false;
     for (;;) {
       while ((unsigned int)t < *prog + (unsigned int)depth && *dseq != stream_seq) {
+        // the kind of step t - 1 (its spread launch stored it ahead of the progress word read above; step t is not
+        // launched yet, so nothing newer can be there)
+        narrow_step = hybrid_ok && !again_wide && skips < 2 && t > t_first && *hint == 1u;
+        again_wide = false;
+        if (narrow_step) cfg->hyb_narrow++;
         // input of unknown order: the first step's launches scanned the lags; the spread launch of the step after it
         // reports what they found (with its progress word) -- stop marching on unsorted / invalid input
         if (check_flags && t_first == 0 && *prog >= 2u && (hflags[0] || hflags[1])) {
@@ -772,6 +799,17 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         stt.n_steps_launched++;
       }
       if (flags_up || *dseq == stream_seq) break;
+      if (hybrid_ok && t > t_first && *need == (unsigned int)t) {
+        // the one-panel launch of step t - 1 met a state at which the full width might batch and evaluated nothing
+        // (its FFT and interpolation launches were no-ops): the same step again, at the full width
+        std::atomic_thread_fence(std::memory_order_acquire);
+        *need = 0u;
+        --t;
+        ++skips;
+        cfg->hyb_skips++;
+        again_wide = true;
+        continue;
+      }
       if ((++spins & 0x3fff) == 0) {
         hipError_t q = hipStreamQuery(st);
         if (q == hipSuccess && *dseq != stream_seq && *prog + (unsigned int)depth <= (unsigned int)t)
@@ -780,6 +818,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    narrow_step = false;
     cfg->stats.n_syncs++;
     if (cfg->h_status->flags[1] & 2) return fail(SK_EHIP, "internal error: inconsistent device state detected by a kernel guard");
     if (!flags_up && check_flags && (cfg->h_status->flags[0] || cfg->h_status->flags[1])) flags_up = true;
@@ -939,6 +978,7 @@ static int kernel_values_device_impl(sk_config* cfg, const double* d_xs, size_t 
                                      double* d_errs, hipStream_t st, int order = SK_ORDER_UNKNOWN,
                                      hipEvent_t lags_ready = nullptr) {
   std::memset(&cfg->stats, 0, sizeof(cfg->stats));
+  cfg->hyb_narrow = cfg->hyb_skips = 0;
   cfg->trace_len = 0;
   cfg->trace_valid = false;
   if (n == 0) return SK_OK;
@@ -1647,6 +1687,13 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
   return rc;
 }
 
+int sk_last_step_kinds(const sk_config* cfg, long long* out2) {
+  if (!cfg || !out2) return fail(SK_EINVAL, "null argument");
+  out2[0] = cfg->hyb_narrow;
+  out2[1] = cfg->hyb_skips;
+  return SK_OK;
+}
+
 int sk_last_host_timing(const sk_config* cfg, double* ms4) {
   if (!cfg || !ms4) return fail(SK_EINVAL, "null argument");
   for (int i = 0; i < 4; ++i) ms4[i] = cfg->host_timing[i];
@@ -2002,7 +2049,7 @@ int sk_launch_floor(sk_config* cfg, int reps, double* us4) {
     for (int q = 0; q < count; ++q) {
       if (which == 0) launch_empty(grid, st);
       else if (which == 1) launch_spread_b(cfg->dc, cfg->d_ec, dbf, SK_MODE_ASIS, 0, nfl, 0.0, 0.0, 0u, st);
-      else launch_interp_b(cfg->dc, cfg->d_ec, dbf, 0, nfl, st);
+      else launch_interp_b(cfg->dc, cfg->d_ec, dbf, 0, nfl, st);  // (a finished state: returns at once)
     }
     (void)hipEventRecord(b, st);
     (void)hipEventSynchronize(b);

@@ -109,6 +109,7 @@ struct sk_config {
   size_t trace_len = 0;
   bool trace_valid = false;
   long long* h_nuniq = nullptr;
+  long long hyb_narrow = 0, hyb_skips = 0;  // last call: steps launched with the one-panel kernels inside a full-width march / skipped by them
   double* h_scal = nullptr;        // pinned scalars handed to small asynchronous uploads
   double* h_fvpin[2] = {nullptr, nullptr};  // callback SDFs: pinned copies of the integrand values of a pass
   hipStream_t own_stream = nullptr;

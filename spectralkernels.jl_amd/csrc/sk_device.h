@@ -137,6 +137,8 @@ struct DevConst {
                                 // one-panel march re-derives (after its tiles) to notice an input that would batch; 0: no check
   int guess_mode;               // 0: runs extended on the certain criterion or the guess; 1: always extended
                                 // (SK_BATCH_GUESS=always: tests drive the re-run and output-fix paths); 2: certain only
+  int hybrid;                   // K = 1 launch inside a full-width march (the peel: one fresh outer panel per step): a state at
+                                // which the full width might batch is skipped, not evaluated (BatchInfo::skip)
 };
 
 // ES-kernel tables (device memory; every workgroup stages them in LDS):
@@ -195,6 +197,11 @@ struct BatchInfo {
   int mixed;
   int probe;           // one-panel march under the automatic batch width: the full width could batch at this step -- its
                        // decision is re-derived after the tiles (batch_probe_full), off the critical path
+  // one-panel kernels inside a full-width march (DevConst::hybrid, sk_api.cpp): peel = this step is a single fresh outer
+  // panel because the march is retiring lags -- the host launches the NEXT step with the lighter K = 1 instantiations;
+  // skip = such a launch met a state at which the full width might batch: nothing is evaluated or published, the host
+  // launches the step again at the full width (only ever set in the LDS copy of a skipping launch)
+  int peel, skip;
   double push_a, push_b;
   double Cx0, dCx;     // centre of slot 0, centre step per slot (-2X: siblings, +2X: outer run)
   double pa[kBatchMax], pb[kBatchMax];  // the reference's bounds of every slot (trace, bisection)
@@ -236,6 +243,7 @@ struct DevState {
   // automatic batch width (sk_api.cpp): n_multi = steps built with more than one slot (applied or not); would_batch: a
   // one-panel march (K = 1 instantiation, dc.Kv > 1) reached a state at which the full width would have built one
   int n_multi, would_batch;
+  int step_id, pad_step;         // the step this state describes: k_interp_b(t) evaluates nothing on any other (a skipped launch)
   BatchInfo bt;
 };
 
@@ -280,6 +288,10 @@ struct HostStatus {
   // has derived state_t, and when that state says "done" copies it into `state` and stores the call's tag in `done_seq`
   unsigned int progress;
   unsigned int done_seq;
+  // one-panel launches inside a full-width march: peel_hint = BatchInfo::peel of the step that stored `progress` last
+  // (written ahead of it); need_wide = t + 1: the one-panel launch of step t skipped it (BatchInfo::skip)
+  unsigned int peel_hint;
+  unsigned int need_wide;
 };
 
 struct DevBuffers {
@@ -354,7 +366,7 @@ void launch_spread_b(const DevConst& dc, const EsConst* ec, const DevBuffers& db
 // INVARIANT of every interpolation launch (k_interp2, k_interp_b, k_joint_interp): db.xs holds at least n valid doubles.
 // The kernels request xs[min(i, n-1)] and the block's first / last lags AHEAD of the state (to overlap the two round
 // trips), so even a launch whose state says "done" or belongs to another lag set reads them.
-void launch_interp_b(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int slot, long long n, hipStream_t st);
+void launch_interp_b(const DevConst& dc, const EsConst* ec, const DevBuffers& db, int t, long long n, hipStream_t st);
 void launch_advance_b(const DevConst& dc, const DevBuffers& db, int mode, int t, long long n, double k0, double ks0,
                       unsigned int seq, hipStream_t st);
 // outputs of lags [lo, hi) from the running sums in buffer `conf` (a march that ended with a pending fix)
