@@ -784,6 +784,8 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         // the kind of step t - 1 (its spread launch stored it ahead of the progress word read above; step t is not
         // launched yet, so nothing newer can be there)
         narrow_step = hybrid_ok && !again_wide && skips < 2 && t > t_first && *hint == 1u;
+        // (tests: every step first with the one-panel kernels, whatever the hint -- they skip what they cannot take)
+        if (hybrid_ok && !again_wide && t > t_first + 1 && getenv("SK_HYBRID_FORCE")) narrow_step = true;
         again_wide = false;
         if (narrow_step) cfg->hyb_narrow++;
         // input of unknown order: the first step's launches scanned the lags; the spread launch of the step after it

@@ -251,3 +251,53 @@ def test_automatic_batch_width_gives_results_that_depend_on_the_input_only(sk, k
         assert seen_narrow
 
 
+
+
+HYBRID_CASES = [
+    # the C5 pattern: a few full-width steps of outer runs, then a long peel of one-panel steps
+    ("c5_peel", (2.14, 0.97, 0.89), dict(tol=1e-12, quadspec=(256, 16)), lambda: np.linspace(0.0, 5.1, 20001)),
+    # default rule (K = 2), log-spaced lags: a short march with a retiring tail
+    ("default_rule", (2.05, 2.6, 0.67), dict(tol=1e-8), lambda: 10.0 ** np.linspace(-5, 1, 30000)),
+    # many small panels, bisections in between (slow decay)
+    ("small_rule_long", (2.99, 2.61, 0.68), dict(tol=1e-10, quadspec=(128, 8)), lambda: 10.0 ** np.linspace(-5, 1, 15000)),
+    # singular SDF: Jacobi first panel and its bisection (mixed sibling pairs), then retiring panels
+    ("singular", (1.0, 1e-3, 1.5), dict(alpha=0.4, quadspec=(64, 4)), lambda: 10.0 ** np.linspace(-6, 0, 8000)),
+]
+
+
+@pytest.mark.parametrize("name,prm,kw,lags", HYBRID_CASES, ids=[c[0] for c in HYBRID_CASES])
+def test_one_panel_launches_inside_a_full_width_march_give_the_full_widths_bits(sk, name, prm, kw, lags, monkeypatch):
+    """Automatic batch width, second half (sk_api.cpp, run_core): while the march retires lags every step is one fresh
+    outer panel (src/adaptive.jl:149-199) and the host launches the NEXT step with the lighter one-panel instantiations
+    (HostStatus::peel_hint); a step they cannot take -- the full width might batch there -- is skipped on the device and
+    launched again at the full width (HostStatus::need_wide).  Whatever mixture of launches a call saw, schedule, values
+    and error estimates are the explicit full width's, bit for bit.  SK_HYBRID_FORCE launches EVERY step with the
+    one-panel kernels first: the skip / relaunch path at every step that is not a peel step."""
+    K = _full_width(kw)
+    auto = sk.AdaptiveKernelConfig(sk.SDF.matern(*prm), **kw)
+    full = sk.AdaptiveKernelConfig(sk.SDF.matern(*prm), batch_panels=K, **kw)
+    k0 = sk.compute_k0(auto)
+    xs = lags()
+    kf, ef = sk.kernel_values(full, xs, k0=k0)
+    sched_f, st_f = _sched(full), full.last_stats()
+    assert sk.step_kinds(full) == dict(one_panel_launches=0, skipped=0)
+    seen = {}
+    for mode in ("plain", "plain", "forced", "plain", "off"):
+        if mode == "forced":
+            monkeypatch.setenv("SK_HYBRID_FORCE", "1")
+        else:
+            monkeypatch.delenv("SK_HYBRID_FORCE", raising=False)
+        cfg = sk.AdaptiveKernelConfig(sk.SDF.matern(*prm), batch_panels=K, **kw) if mode == "off" else auto
+        k, e = sk.kernel_values(cfg, xs, k0=k0)
+        st, kinds = cfg.last_stats(), sk.step_kinds(cfg)
+        assert _sched(cfg) == sched_f, (name, mode)
+        assert np.array_equal(k, kf) and np.array_equal(e, ef, equal_nan=True), (name, mode, kinds)
+        assert st["n_steps"] == st_f["n_steps"] and st["n_panels"] == st_f["n_panels"], (name, mode)
+        # launched in vain: the step queued behind the last one, the one whose launch reported "done", every skipped one
+        assert st["n_steps_launched"] <= st["n_steps"] + st["n_rerun"] + 2 + kinds["skipped"], (name, mode, st, kinds)
+        seen[mode] = kinds
+    if name == "c5_peel":
+        assert seen["plain"]["one_panel_launches"] >= 20 and seen["plain"]["skipped"] <= 2, seen
+    assert seen["forced"]["one_panel_launches"] >= seen["plain"]["one_panel_launches"], seen
+    if st_f["n_steps"] < st_f["n_panels"]:  # the march batches somewhere: forced one-panel launches must have been skipped there
+        assert seen["forced"]["skipped"] >= 1, seen
