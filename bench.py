@@ -275,6 +275,7 @@ def main():
     dt = dt_local
     per_rank = None
     st = cfg.last_stats()
+    kinds = sk.step_kinds(cfg)
     if dist is not None:
         t = torch.tensor([dt_local, float(st["n_panels"]), float(st["n_outer"]), float(n), float(st["sum_active"])],
                          dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -558,7 +559,10 @@ def main():
                           "nufft_width": cfg.nufft_width},
                "max_rel_err_vs_closed_form": max_rel_err,
                "panels": {"outer": st["n_outer"], "nufft_pairs": st["n_panels"], "abar": abar, "steps": st["n_steps"],
-                          "steps_rerun": st["n_rerun"], "steps_launched": st["n_steps_launched"], "host_syncs": st["n_syncs"]},
+                          "steps_rerun": st["n_rerun"], "steps_launched": st["n_steps_launched"], "host_syncs": st["n_syncs"],
+                          # launches of the last march that ran the one-panel kernels inside a full-width march / that
+                          # those kernels skipped (launched again at the full width): DESIGN.md 3g
+                          "one_panel_launches": kinds["one_panel_launches"], "one_panel_skipped": kinds["skipped"]},
                "rccl_ranks": world if (dist is not None and args.backend == "nccl") else 0, "per_rank": per_rank,
                "host_to_host": host, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
