@@ -133,6 +133,10 @@ int sk_last_host_timing(const sk_config* cfg, double* ms4);
  * (while the march retires lags every step is one fresh outer panel, src/adaptive.jl:149-199: the lighter instantiations
  * evaluate it with the same bits), [1] steps those launches skipped and the host launched again at the full width. */
 int sk_last_step_kinds(const sk_config* cfg, long long* out2);
+/* Host threads the library's teams are sized by: the smaller of this process's CPU affinity mask and its cgroup CPU
+ * quota (cpu.max / cfs_quota_us), at most `cap` (cap <= 0: no cap).  The staging copies, rule builders and shard scans
+ * use min(8, that); an OpenMP team sized by the CPUs a container merely shows is throttled under a quota. */
+int sk_host_threads(int cap);
 
 /* Memory owned by the library's HIP runtime, so that a caller (the Julia shim, tests, bench.py) needs no HIP
  * binding of its own.  sk_host_alloc returns PINNED host memory: arrays that live in it are copied by DMA

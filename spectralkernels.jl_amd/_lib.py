@@ -72,6 +72,7 @@ def load():
     L.sk_panel_sums.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_double, vp, C.c_size_t, C.c_int, vp, vp]
     L.sk_last_host_timing.argtypes = [vp, dp]
     L.sk_last_step_kinds.argtypes = [vp, C.POINTER(C.c_longlong)]
+    L.sk_host_threads.argtypes = [C.c_int]
     L.sk_device_count.argtypes = [C.POINTER(C.c_int)]
     L.sk_device_malloc.argtypes = [C.POINTER(vp), C.c_size_t, C.c_int]
     L.sk_device_free.argtypes = [vp]

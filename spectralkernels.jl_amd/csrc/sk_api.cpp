@@ -1689,6 +1689,8 @@ int sk_kernel_values(sk_config* cfg, const double* xs, size_t n, double k0, int 
   return rc;
 }
 
+int sk_host_threads(int cap) { return host_threads(cap); }
+
 int sk_last_step_kinds(const sk_config* cfg, long long* out2) {
   if (!cfg || !out2) return fail(SK_EINVAL, "null argument");
   out2[0] = cfg->hyb_narrow;

@@ -12,7 +12,7 @@ module SpectralKernelsHIP
 export AdaptiveKernelConfig, kernel_values, kernel_values!, kernel_values_multi, kernel_values_joint, kernel_values_pairs,
        kernel_jacobian_pairs, build_dense_cov_matrix, compute_k0, gen_derivative_config, gen_new_sdf_config, recognize_sdf,
        pinned_vector, ShardedKernelConfig, MaternSDF, ExponentialSDF, GaussianSDF, sdf_derivative, check_abi,
-       kernel_values_device!, kernel_values_pairs_device!, set_split!, last_shard_stats
+       kernel_values_device!, kernel_values_pairs_device!, set_split!, last_shard_stats, last_step_kinds, host_threads
 
 const LIB = get(ENV, "SPECTRALKERNELS_HIP_LIB",
                 joinpath(@__DIR__, "..", "libspectralkernels_hip.so"))
@@ -562,5 +562,16 @@ function last_shard_stats(sh::ShardedKernelConfig, shard::Integer)
                sh.handle, shard, st, ms, lo, hi))
   (stats=st[], ms=ms[], lo=lo[], hi=hi[])
 end
+
+"""Automatic batch width, last march on `cfg`: launches that ran the one-panel kernels inside a full-width march, and the
+steps those launches skipped (launched again at the full width) -- sk_last_step_kinds."""
+function last_step_kinds(cfg::AdaptiveKernelConfig)
+  out = zeros(Clonglong, 2)
+  _check(ccall((:sk_last_step_kinds, LIB), Cint, (Ptr{Cvoid}, Ptr{Clonglong}), cfg.handle, out))
+  (one_panel_launches=Int(out[1]), skipped=Int(out[2]))
+end
+
+"Host threads the library sizes its teams by (affinity mask and cgroup CPU quota, at most `cap`) -- sk_host_threads."
+host_threads(cap::Integer=0) = Int(ccall((:sk_host_threads, LIB), Cint, (Cint,), cap))
 
 end # module

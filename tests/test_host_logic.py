@@ -186,3 +186,24 @@ def test_abi_struct_layouts_match_the_mirrors():
         m = re.search(r"const %s = \(([^)]*)\)" % name, jl)
         assert m, name
         assert [int(x) for x in m.group(1).replace(" ", "").split(",") if x] == _lib.abi_layout(which), name
+
+
+def test_host_threads_follow_the_affinity_mask():
+    """sk_host_threads (csrc/sk_rules.cpp, host_threads): every OpenMP team of the library is sized by what the process
+    may really run -- its affinity mask and its cgroup CPU quota -- not by the CPUs the box shows (a 256-thread team under
+    a quota of 16 CPUs is throttled: DESIGN.md 4).  The mask half is checked here in a fresh process (the value is cached
+    on first use); the quota half reads /sys/fs/cgroup, which a test cannot fake."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, ctypes\n"
+        "cpus = sorted(os.sched_getaffinity(0))\n"
+        "os.sched_setaffinity(0, set(cpus[:2]))\n"
+        "lib = ctypes.CDLL(sys.argv[1])\n"
+        "lib.sk_host_threads.argtypes = [ctypes.c_int]\n"
+        "print(len(cpus[:2]), lib.sk_host_threads(0), lib.sk_host_threads(8), lib.sk_host_threads(1))\n")
+    lib = os.path.join(ROOT, "spectralkernels.jl_amd", "libspectralkernels_hip.so")
+    out = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-400:]
+    n, t0, t8, t1 = (int(v) for v in out.stdout.split())
+    assert 1 <= t0 <= n and t8 == t0 and t1 == 1, out.stdout
