@@ -656,6 +656,8 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
   // step before -- never of timing -- and every evaluated step has the full width's bits: the result is the full-width
   // march's, bit for bit (tests/test_gpu_batched.py).  After two skipped steps a call stays at the full width.
   const bool hybrid_ok = batched && cfg->k_adaptive && cfg->k_full > 1 && cfg->dc.K == cfg->k_full && cfg->plan_b1 && !g_no_hybrid;
+  // (tests: every step first with the one-panel kernels, whatever the hint -- they skip what they cannot take)
+  const bool hybrid_force = hybrid_ok && getenv("SK_HYBRID_FORCE") != nullptr;
   bool narrow_step = false;
   DevConst dcn = cfg->dc;
   dcn.K = 1;
@@ -784,8 +786,7 @@ static int run_core(sk_config* cfg, const double* d_uxs, long long n, double k0,
         // the kind of step t - 1 (its spread launch stored it ahead of the progress word read above; step t is not
         // launched yet, so nothing newer can be there)
         narrow_step = hybrid_ok && !again_wide && skips < 2 && t > t_first && *hint == 1u;
-        // (tests: every step first with the one-panel kernels, whatever the hint -- they skip what they cannot take)
-        if (hybrid_ok && !again_wide && t > t_first + 1 && getenv("SK_HYBRID_FORCE")) narrow_step = true;
+        if (hybrid_force && !again_wide && t > t_first + 1) narrow_step = true;
         again_wide = false;
         if (narrow_step) cfg->hyb_narrow++;
         // input of unknown order: the first step's launches scanned the lags; the spread launch of the step after it
